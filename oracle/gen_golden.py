@@ -1,0 +1,323 @@
+"""Generate golden fixtures by RUNNING THE REFERENCE (container only).
+
+TEST INFRASTRUCTURE.  Usage (from the repo root, in the build container where
+/root/reference exists):   python -m oracle.gen_golden
+
+Imports the unmodified reference package through ``oracle/refshim.py`` and stores
+inputs + outputs for every row of SURVEY.md section 8a as small ``.npz`` files under
+``tests/golden/``.  Only data is written: no reference source text leaves the
+container.  ``tests/test_oracle_golden.py`` pins ``oracle/pgm.py`` against these
+files; the ``-m gpu`` tests pin the HIP path against them too.
+
+Frames are float64 unless the name says f32 (numpy 2.x runs float32 FFTs in single
+precision while the numpy the reference was written for up-cast).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle.refshim import load_reference  # noqa: E402
+from scarlet_amd import synth  # noqa: E402
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def gen_fft(sc):
+    fft = sc.fft
+    g = lambda s: sc.psf.generate_psf_image(sc.psf.gaussian, (41, 41), sigma=s)
+    p1, p2 = g(1.0), g(2.0)
+    k12 = fft.match_psfs(p2, p1)
+    k21 = fft.match_psfs(p1, p2)
+    rng = np.random.RandomState(3)
+    img = rng.rand(3, 23, 30)
+    ker = rng.rand(3, 7, 9)
+    conv = fft.convolve(fft.Fourier(img), fft.Fourier(ker), axes=(1, 2)).image
+    shapes_in = np.array([[58, 43], [48, 43], [64, 41], [128, 41], [61, 61], [33, 33], [67, 8], [72, 3]])
+    shapes_out = np.array([fft._get_fft_shape(np.zeros((a, a)), np.zeros((b, b)), 3)
+                           for a, b in shapes_in])
+    save("fft", psf1=p1.image, psf2=p2.image, k12=k12.image, k21=k21.image,
+         img=img, ker=ker, conv=conv, shapes_in=shapes_in, shapes_out=shapes_out)
+
+
+def gen_monotonic(sc):
+    op = sc.operator
+    out = {}
+    cases = [((5, 5), (2, 2)), ((9, 11), (2, 7)), ((33, 29), (10, 20)), ((16, 16), (8, 8))]
+    rng = np.random.RandomState(11)
+    for n, (shape, c) in enumerate(cases):
+        sc.cache.Cache._cache = {}
+        w = op.getRadialMonotonicWeights(shape, useNearest=False, center=c)
+        out["w%d" % n] = w
+        out["shape%d" % n] = np.array(shape)
+        out["center%d" % n] = np.array(c)
+        for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+            for th in (0.0, 0.1):
+                X = (rng.rand(*shape) + np.exp(-((np.arange(shape[0])[:, None] - c[0]) ** 2 +
+                                                 (np.arange(shape[1])[None, :] - c[1]) ** 2) / 20.)).astype(dt)
+                out["x%d_%s_%g" % (n, tag, th)] = X.copy()
+                prox = op.prox_strict_monotonic(shape, use_nearest=False, thresh=th, center=c)
+                Y = X.copy()
+                prox(Y, 0)
+                out["y%d_%s_%g" % (n, tag, th)] = Y
+    # nearest-neighbour operator (centred shapes only: the reference ignores `center`
+    # when building it, operator.py:110)
+    for n, shape in enumerate([(5, 5), (9, 9), (11, 15)]):
+        sc.cache.Cache._cache = {}
+        c = ((shape[0] - 1) // 2, (shape[1] - 1) // 2)
+        prox = op.prox_strict_monotonic(shape, use_nearest=True, thresh=0, center=c)
+        X = rng.rand(*shape)
+        Y = X.copy()
+        prox(Y, 0)
+        out["nshape%d" % n] = np.array(shape)
+        out["nref%d" % n] = np.array(prox.keywords["ref_idx"])
+        out["nx%d" % n] = X
+        out["ny%d" % n] = Y
+    save("monotonic", **out)
+
+
+def gen_measure(sc):
+    ms = sc.measurement
+    rng = np.random.RandomState(5)
+    psf = sc.psf.generate_psf_image(sc.psf.gaussian, (41, 41), amplitude=1, sigma=.9, normalize=False).image
+    psf /= psf.max()
+    out = {"psf": psf}
+    H, W = 40, 36
+    yy, xx = np.mgrid[:H, :W]
+    cents = [(20, 18), (5, 30), (37, 3), (12, 12), (21, 33), (2, 2), (38, 34)]
+    for n, (cy, cx) in enumerate(cents):
+        m = np.exp(-((yy - cy - 0.3) ** 2 + (xx - cx + 0.2) ** 2) / 8.) + 0.05 * rng.rand(H, W)
+        out["m%d" % n] = m
+        out["c%d" % n] = np.array((cy, cx))
+        mp = ms.max_pixel(m, (cy, cx))
+        out["maxpix%d" % n] = np.array(mp)
+        nc, sh = ms.psf_weighted_centroid(m, psf, mp)
+        out["cen%d" % n] = np.array(nc)
+        out["shift%d" % n] = np.array(sh)
+        m32 = m.astype(np.float32)
+        nc, sh = ms.psf_weighted_centroid(m32, psf, ms.max_pixel(m32, (cy, cx)))
+        out["cen32_%d" % n] = np.array(nc)
+        out["shift32_%d" % n] = np.array(sh)
+    out["n"] = np.array(len(cents))
+    save("measure", **out)
+
+
+def gen_symmetry(sc):
+    op = sc.operator
+    rng = np.random.RandomState(7)
+    out = {}
+    cases = [((21, 21), (8, 13), (0.21, -0.37)), ((32, 30), (16, 15), (0.4, 0.1)),
+             ((32, 30), (10, 22), (-0.49, 0.05)), ((64, 64), (30, 40), (0.013, -0.3)),
+             ((17, 24), (3, 20), (0.3, 0.3)), ((64, 64), (33, 31), (0.25, 0.5)),
+             ((31, 33), (15, 16), (0.3, 0.2))]
+    for n, (shape, c, sh) in enumerate(cases):
+        yy, xx = np.mgrid[:shape[0], :shape[1]]
+        X = np.exp(-((yy - c[0] + sh[0]) ** 2 + (xx - c[1] + sh[1]) ** 2) / 10.) + .1 * rng.rand(*shape) - .03
+        out["x%d" % n] = X
+        out["shape%d" % n] = np.array(shape)
+        out["center%d" % n] = np.array(c)
+        out["shift%d" % n] = np.array(sh)
+        for alg in ("kspace", "soft", "sdss"):
+            for fill in (None, 0.0):
+                Y = X.copy()
+                op.prox_uncentered_symmetry(Y, 0, center=c, algorithm=alg, fill=fill,
+                                            shift=np.array(sh), strength=.5)
+                out["y%d_%s_%s" % (n, alg, "fill" if fill is not None else "nofill")] = Y
+        # zero shift falls back to soft symmetry at strength 1 (operator.py:337-339)
+        Y = X.copy()
+        op.prox_uncentered_symmetry(Y, 0, center=c, algorithm="kspace", shift=np.array((0., 0.)))
+        out["y%d_zero" % n] = Y
+        Y = X.copy()
+        op.prox_uncentered_symmetry(Y, 0, center=c, algorithm="kspace", shift=None)
+        out["y%d_none" % n] = Y
+        # the bare k-space operator on a centred odd window
+    W = rng.rand(21, 27)
+    out["kx"] = W
+    out["ky"] = op.prox_kspace_symmetry(W, 0, shift=(0.3, -0.45))
+    W2 = rng.rand(20, 26)
+    out["kx2"] = W2
+    out["ky2"] = op.prox_kspace_symmetry(W2, 0, shift=(-0.2, 0.15))
+    out["n"] = np.array(len(cases))
+    save("symmetry", **out)
+
+
+def _blend_state(blend):
+    comps = blend.components
+    return dict(sed=np.array([c.sed for c in comps]), morph=np.array([c.morph for c in comps]),
+                center=np.array([c.pixel_center for c in comps]).astype(np.int64),
+                shift=np.array([c.shift for c in comps]).astype(np.float64),
+                flags=np.array([c.flags.value for c in comps]),
+                mse=np.array(blend.mse, dtype=np.float64))
+
+
+def gen_grad(sc):
+    """loss / gradient / Lipschitz / convergence on a small scene, with and without PSF."""
+    rng = np.random.RandomState(13)
+    B, H, W, K = 3, 21, 25, 2
+    images = rng.rand(B, H, W)
+    seds = rng.rand(K, B) + .5
+    morphs = rng.rand(K, H, W)
+    weights = rng.rand(B, H, W) + .5
+    out = dict(images=images, seds=seds, morphs=morphs, weights=weights)
+    g = lambda s, n: sc.psf.generate_psf_image(sc.psf.gaussian, (n, n), sigma=s).image
+    tpsf = g(.8, 11)[None]
+    opsf = np.array([g(1.1 + .2 * b, 11) for b in range(B)])
+    out["tpsf"], out["opsf"] = tpsf, opsf
+    for tag, use_psf, w in (("nopsf", False, 1), ("nopsf_w", False, weights),
+                            ("psf", True, 1), ("psf_w", True, weights)):
+        if use_psf:
+            frame = sc.Frame(images.shape, psfs=tpsf.copy(), dtype=np.float64)
+            obs = sc.Observation(images, psfs=opsf.copy(), weights=None if w is 1 else w).match(frame)
+        else:
+            frame = sc.Frame(images.shape, dtype=np.float64)
+            obs = sc.Observation(images, weights=None if w is 1 else w).match(frame)
+        comps = [sc.Component(frame, seds[k].copy(), morphs[k].copy()) for k in range(K)]
+        blend = sc.Blend(comps, obs)
+        blend._backward()
+        out["loss_" + tag] = np.array(blend.mse[-1])
+        out["gsed_" + tag] = np.array([c.sed_grad for c in comps])
+        out["gmorph_" + tag] = np.array([c.morph_grad for c in comps])
+        out["render_" + tag] = obs.render(blend.get_model())
+        if use_psf:
+            out["diff_" + tag] = obs._diff_kernels.image
+        blend._set_lipschitz(False)
+        out["L_exact_" + tag] = np.array([blend.L_sed, blend.L_morph])
+        blend._set_lipschitz(True)
+        out["L_approx_" + tag] = np.array([blend.L_sed, blend.L_morph])
+    save("grad", **out)
+
+
+def gen_fit_hsc(sc):
+    """BASELINE config 1: data/hsc_cosmos_35.npz, rows 0-1, 50 iterations, e_rel=0."""
+    d = np.load("/root/reference/data/hsc_cosmos_35.npz")
+    cat = d["catalog"]
+    pix = np.array([(int(cat["y"][i]), int(cat["x"][i])) for i in range(2)])
+    out = {"pixels": pix}
+    # the inputs themselves (data, 5x58x48 float32 + 5x43x43 PSFs) so that the tests and the
+    # GPU box can rebuild config 1 without /root/reference
+    save("hsc_inputs", images=d["images"], psfs=d["psfs"].astype(np.float32),
+         catalog_yx=np.array([(cat["y"][i], cat["x"][i]) for i in range(len(cat))]))
+    for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+        images = d["images"].astype(dt)
+        psfs = d["psfs"] / d["psfs"].sum(axis=(1, 2))[:, None, None]
+        psfs = psfs.astype(dt)
+        mpsf = sc.psf.generate_psf_image(sc.psf.gaussian, (43, 43), sigma=.9).image[None].astype(dt)
+        frame = sc.Frame(images.shape, psfs=mpsf.copy(), dtype=dt)
+        obs = sc.Observation(images, psfs=psfs.copy()).match(frame)
+        bg = np.ones(5) * 0.1
+        srcs = [sc.ExtendedSource(frame, tuple(p), obs, bg) for p in pix]
+        out["init_sed_" + tag] = np.array([s.sed for s in srcs])
+        out["init_morph_" + tag] = np.array([s.morph for s in srcs])
+        out["init_center_" + tag] = np.array([s.pixel_center for s in srcs]).astype(np.int64)
+        out["init_shift_" + tag] = np.array([s.shift for s in srcs])
+        blend = sc.Blend(srcs, obs)
+        blend.fit(50, e_rel=0)
+        for k, v in _blend_state(blend).items():
+            out[k + "_" + tag] = v
+        if tag == "f64":
+            out["model_psf"] = mpsf
+            out["obs_psfs"] = psfs
+            out["diff_kernel"] = obs._diff_kernels.image
+    save("fit_hsc", **out)
+
+
+def gen_fit_synth(sc):
+    """BASELINE config 2 shaped scenes (5x64x64, K=4, no PSF): init + 30 iterations.
+    Also a run with e_rel=1e-3 (ragged stop), one with approximate_L, one with L0."""
+    out = {}
+    for idx in (0, 1, 2):
+        scn = synth.make_scene(idx)
+        for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+            images = scn["images"].astype(dt)
+            frame = sc.Frame(images.shape, dtype=dt)
+            obs = sc.Observation(images).match(frame)
+            bg = np.ones(5) * 0.1
+            srcs = [sc.ExtendedSource(frame, tuple(int(v) for v in p), obs, bg) for p in scn["centers"]]
+            pre = "s%d_%s_" % (idx, tag)
+            out[pre + "init_sed"] = np.array([s.sed for s in srcs])
+            out[pre + "init_morph"] = np.array([s.morph for s in srcs])
+            out[pre + "init_center"] = np.array([s.pixel_center for s in srcs]).astype(np.int64)
+            out[pre + "init_shift"] = np.array([s.shift for s in srcs])
+            blend = sc.Blend(srcs, obs)
+            blend.fit(30, e_rel=0)
+            for k, v in _blend_state(blend).items():
+                out[pre + k] = v
+            # snapshots after 1 iteration for step-level parity
+            srcs1 = [sc.ExtendedSource(frame, tuple(int(v) for v in p), obs, bg) for p in scn["centers"]]
+            b1 = sc.Blend(srcs1, obs)
+            b1.fit(1, e_rel=0)
+            for k, v in _blend_state(b1).items():
+                out[pre + "it1_" + k] = v
+    # ragged stop + approximate_L on scene 0, f32
+    scn = synth.make_scene(0)
+    images = scn["images"]
+    frame = sc.Frame(images.shape, dtype=np.float32)
+    obs = sc.Observation(images).match(frame)
+    bg = np.ones(5) * 0.1
+    for tag, kw in (("erel", dict(max_iter=200, e_rel=1e-2)),
+                    ("approx", dict(max_iter=30, e_rel=0, approximate_L=True))):
+        srcs = [sc.ExtendedSource(frame, tuple(int(v) for v in p), obs, bg) for p in scn["centers"]]
+        blend = sc.Blend(srcs, obs)
+        blend.fit(**kw)
+        for k, v in _blend_state(blend).items():
+            out["s0_f32_%s_%s" % (tag, k)] = v
+        out["s0_f32_%s_it" % tag] = np.array(blend.it)
+    save("fit_synth", **out)
+
+
+def gen_update(sc):
+    """update.* with bbox arguments and sparsity (rows a10/a14/a15 untested upstream)."""
+    upd = sc.update
+    rng = np.random.RandomState(17)
+    shape = (5, 24, 28)
+    frame = sc.Frame(shape, dtype=np.float64)
+    morph = rng.rand(24, 28) - .1
+    sed = rng.rand(5)
+    bbox = sc.bbox.Box.from_bounds(4, 19, 6, 25)
+    out = dict(morph=morph, sed=sed, bbox=np.array([4, 19, 6, 25]), center=np.array([11, 14]))
+    c = sc.Component(frame, sed.copy(), morph.copy())
+    c.L_morph = 2.
+    upd.monotonic(c, (11, 14), bbox=bbox)
+    out["mono_bbox"] = c.morph.copy()
+    c = sc.Component(frame, sed.copy(), morph.copy())
+    c.L_morph = 2.
+    c.shift = np.array((0.2, -0.1))
+    upd.symmetric(c, (11, 14), bbox=bbox)
+    out["sym_bbox"] = c.morph.copy()
+    c = sc.Component(frame, sed.copy(), morph.copy())
+    c.L_morph = 2.
+    upd.sparse_l0(c, thresh=.5)
+    out["l0"] = c.morph.copy()
+    c = sc.Component(frame, sed.copy(), morph.copy())
+    c.L_morph = 2.
+    upd.sparse_l1(c, thresh=.5)
+    out["l1"] = c.morph.copy()
+    save("update", **out)
+
+
+def main():
+    sc = load_reference()
+    import scarlet.cache
+    sc.cache = scarlet.cache
+    gen_fft(sc)
+    gen_monotonic(sc)
+    gen_measure(sc)
+    gen_symmetry(sc)
+    gen_grad(sc)
+    gen_update(sc)
+    gen_fit_hsc(sc)
+    gen_fit_synth(sc)
+
+
+if __name__ == "__main__":
+    main()

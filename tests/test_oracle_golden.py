@@ -1,0 +1,399 @@
+"""Pin the CPU oracle (oracle/pgm.py + oracle/sweeps.c) against
+(a) golden vectors held by the reference's own tests and
+(b) fixtures produced by running the reference (oracle/gen_golden.py).
+CPU only; no GPU, no /root/reference needed."""
+import numpy as np
+import pytest
+from numpy.testing import assert_almost_equal, assert_array_equal, assert_allclose
+
+from conftest import load_golden, rel_err
+from oracle import pgm, native
+from scarlet_amd import synth
+
+
+# ---------------------------------------------------------------- reference test vectors
+def test_next_fast_len_matches_scipy():
+    import scipy.fftpack
+    for n in list(range(1, 400)) + [511, 512, 513, 640, 1000, 1023]:
+        assert pgm.next_fast_len(n) == scipy.fftpack.next_fast_len(n), n
+
+
+def test_pad_center_layouts():
+    # reference tests/test_fft.py:9-68
+    a = pgm.pad_to(np.ones((1, 1)), (5, 4))
+    truth = np.zeros((5, 4)); truth[2, 2] = 1
+    assert_array_equal(a, truth)
+    assert np.fft.ifftshift(a)[0, 0] == 1
+    a0 = np.arange(10).reshape(5, 2)
+    ap = pgm.pad_to(a0, (9, 11))
+    truth = np.zeros((9, 11), dtype=int)
+    truth[2:7, 5:7] = a0
+    assert_array_equal(ap, truth)
+    assert_array_equal(pgm.centered(ap, (5, 2)), a0)
+    with pytest.raises(ValueError):
+        pgm.centered(a0, (6, 2))
+
+
+def test_weighted_monotonic_5x5_reference_vectors():
+    # reference tests/test_operator.py:31-56, tests/test_update.py:143-169
+    X = np.arange(25, dtype=np.float64).reshape(5, 5)
+    assert_array_equal(pgm.neighbour_offsets(5), [-6, -5, -4, -1, 1, 4, 5, 6])
+    Y = X.copy()
+    pgm.prox_weighted_monotonic(Y, (2, 2), 0.0)
+    truth = [[0., 1., 2., 3., 4.],
+             [5., 6., 7., 8., 9.],
+             [9.74264069, 11., 12., 12., 10.82842712],
+             [11.0306277, 11.70710678, 12., 12., 11.77123617],
+             [11.55634919, 11.86886724, 11.91421356, 11.98324916, 11.92809042]]
+    assert_almost_equal(Y, truth)
+    Y = X.copy()
+    pgm.prox_weighted_monotonic(Y, (2, 2), 0.25)
+    truth = [[0.000000000, 1.000000000, 2.000000000, 3.000000000, 4.000000000],
+             [5.000000000, 6.000000000, 7.000000000, 7.242640687, 5.806841831],
+             [5.801461031, 9.000000000, 12.000000000, 9.000000000, 6.074431804],
+             [5.895545844, 7.681980515, 9.000000000, 7.681980515, 5.935521488],
+             [4.988519641, 5.949655012, 6.170941546, 5.949655012, 4.997301087]]
+    assert_almost_equal(Y, truth)
+
+
+def test_nearest_monotonic_5x5_reference_vectors():
+    # reference tests/test_operator.py:13-29
+    X = np.arange(25, dtype=np.float64).reshape(5, 5)
+    ref = pgm.nearest_reference((5, 5), (2, 2))
+    assert list(ref) == [6, 7, 7, 7, 8, 11, 12, 12, 12, 13, 11, 12, 12,
+                         12, 13, 11, 12, 12, 12, 13, 16, 17, 17, 17, 18]
+    Y = X.copy()
+    pgm.prox_nearest_monotonic(Y, (2, 2))
+    truth = [[0.0, 1.0, 2.0, 3.0, 4.0],
+             [5.0, 6.0, 7.0, 8.0, 9.0],
+             [10.0, 11.0, 12.0, 12.0, 12.0],
+             [11.0, 12.0, 12.0, 12.0, 12.0],
+             [12.0, 12.0, 12.0, 12.0, 12.0]]
+    assert_array_equal(Y, truth)
+    with pytest.raises(ValueError):
+        pgm.prox_nearest_monotonic(X.copy(), (2, 2), thresh=.25)
+
+
+def test_symmetry_reference_vectors():
+    # reference tests/test_update.py:178-211, tests/test_operator.py:92-123
+    X = np.arange(25, dtype=float).reshape(5, 5)
+    Y = X.copy(); pgm.update_symmetric(Y, (2, 2))
+    assert_array_equal(Y, np.ones_like(X) * 12)
+    Y = X.copy(); pgm.update_symmetric(Y, (2, 2), strength=.5, algorithm="soft")
+    assert_array_equal(Y, np.arange(6, 18.5, .5).reshape(5, 5))
+    Y = X.copy(); pgm.update_symmetric(Y, (1, 1))
+    truth = X.copy(); truth[:3, :3] = 6
+    assert_array_equal(Y, truth)
+    x = np.zeros((21, 21))
+    x[8:13, 8:13] = [[1, 2, 3, 2, 1], [2, 3, 4, 3, 1], [3, 4, 5, 1, 1], [2, 3, 1, 1, 1], [1, 1, 1, 1, 1]]
+    assert_almost_equal(pgm.kspace_symmetry(x, (0, 0)), (x[::-1, ::-1] + x) / 2)
+
+
+def test_uncentered_windows_reference_vectors():
+    # reference tests/test_operator.py:131-219 (prox_plus under the 4 corner windows)
+    for flip in (False, True):
+        x = np.arange(35).reshape(5, 7)
+        if flip:
+            x = x[::-1]
+        x = (x - 5).astype(float)
+        shape = x.shape
+        cases = [((2, 3), (slice(None), slice(None))),
+                 ((1, 2), (slice(0, 3), slice(0, 5))),
+                 ((1, shape[1] - 3), (slice(0, 3), slice(-5, shape[1]))),
+                 ((shape[0] - 2, 2), (slice(-3, shape[0]), slice(0, 5))),
+                 ((shape[0] - 2, shape[1] - 3), (slice(-3, shape[0]), slice(-5, shape[1])))]
+        for c, region in cases:
+            truth = x.copy()
+            truth[region][x[region] < 0] = 0
+            y = x.copy()
+            pgm.uncentered(y, pgm.prox_plus, c)
+            assert_array_equal(y, truth)
+            truthf = np.zeros_like(x)
+            truthf[region][x[region] > 0] = x[region][x[region] > 0]
+            y = x.copy()
+            pgm.uncentered(y, pgm.prox_plus, c, fill=0)
+            assert_array_equal(y, truthf)
+
+
+def test_prox_and_normalize_reference_vectors():
+    # reference tests/test_update.py:23-97
+    sed = np.array([-.1, .1, 4, -.2, .2, 0], dtype=np.float32)
+    assert_array_equal(pgm.prox_plus(sed.copy()), np.array([0, .1, 4, 0, .2, 0], dtype=np.float32))
+    morph = np.arange(25, dtype=float).reshape(5, 5)
+    truth = morph.copy(); truth[0, :-1] = 0
+    assert_array_equal(pgm.prox_hard(morph.copy(), 1.0, 4), truth)
+    truth = np.zeros(25); truth[5:] = np.arange(20) + 1
+    assert_array_equal(pgm.prox_soft(morph.copy(), 2.0, 2), truth.reshape(5, 5))
+    s = np.arange(6, dtype=np.float32); m = np.arange(25, dtype=np.float32).reshape(5, 5)
+    a, b = s.copy(), m.copy(); pgm.normalize(a, b, "sed")
+    assert_array_equal(a, s / 15); assert_array_equal(b, m * 15)
+    a, b = s.copy(), m.copy(); pgm.normalize(a, b, "morph")
+    assert_array_equal(a, s * m.sum()); assert_array_equal(b, m / m.sum())
+    a, b = s.copy(), m.copy(); pgm.normalize(a, b)
+    assert_array_equal(a, s * 24); assert_array_equal(b, m / 24)
+    with pytest.raises(ValueError):
+        pgm.normalize(a, b, "fubar")
+
+
+def test_max_pixel_reference_vectors():
+    # reference tests/test_update.py:11-21
+    morph = np.zeros((15, 15)); morph[4, 7] = 1; morph[11, 9] = 2
+    assert pgm.max_pixel(morph, (5, 5)) == (4, 7)
+
+
+def test_psf_reference_vectors():
+    # reference tests/test_psf.py:90-109
+    psf = pgm.generate_psf_image(pgm.gaussian, (5, 5), normalize=False, amplitude=1, sigma=.5)
+    truth = [[0.0000048820, 0.0005536870, 0.0023856813, 0.0005536870, 0.0000048820],
+             [0.0005536870, 0.0627960770, 0.2705706056, 0.0627960770, 0.0005536870],
+             [0.0023856813, 0.2705706056, 1.1658125164, 0.2705706056, 0.0023856813],
+             [0.0005536870, 0.0627960770, 0.2705706056, 0.0627960770, 0.0005536870],
+             [0.0000048820, 0.0005536870, 0.0023856813, 0.0005536870, 0.0000048820]]
+    assert_almost_equal(psf, truth)
+    psf = pgm.generate_psf_image(pgm.moffat, (5, 5), normalize=False, y0=-1, x0=0, amplitude=1, alpha=2.3)
+    assert_almost_equal(psf[1, 2], 1.5270177289)
+    assert_almost_equal(psf[4, 0], 0.2515929101)
+
+
+def test_detection_coadd_and_init_reference_vectors():
+    # reference tests/test_source.py:95-206
+    shape = (5, 11, 15)
+    x, y = np.meshgrid(np.linspace(-2, 2, 5), np.linspace(-2, 2, 5))
+    r = np.sqrt(x ** 2 + y ** 2)
+    true_sed = np.arange(5)
+    true_morph = np.zeros(shape[1:])
+    cy, cx = (np.array(true_morph.shape) - 1) // 2
+    true_morph[cy - 2:cy + 3, cx - 2:cx + 3] = 3 - r
+    bg = np.ones(5) * 1e-3
+    morph = true_morph.copy(); morph[5, 3] = 10
+    images = true_sed[:, None, None] * morph[None]
+    sed, m = pgm.init_extended_source((cy, cx), images.astype(float), bg)
+    assert_array_equal(sed / 3, true_sed)
+    assert_almost_equal(m * 3, true_morph)
+    morph = true_morph.copy(); morph[5, 5] = 2
+    images = true_sed[:, None, None] * morph[None]
+    sed, m = pgm.init_extended_source((cy, cx), images.astype(float), bg, symmetric=False)
+    t = true_morph.copy(); t[5, 5] = 1.5816233815926433
+    assert_almost_equal(m * 3, t)
+    sed, m = pgm.init_extended_source((cy, cx), images.astype(float), bg, monotonic=False)
+    assert_almost_equal(m * 3, true_morph)
+    with pytest.raises(ValueError):
+        pgm.detection_coadd(true_sed + 1., np.zeros(5), images)
+
+
+# ------------------------------------------------------------------- generated fixtures
+def test_fft_fixture():
+    g = load_golden("fft")
+    for (a, b), out in zip(g["shapes_in"], g["shapes_out"]):
+        assert pgm.fft_shape((a, a), (b, b), 3) == list(out)
+    p1 = pgm.generate_psf_image(pgm.gaussian, (41, 41), sigma=1.0)
+    assert_allclose(p1, g["psf1"], rtol=0, atol=1e-15)
+    assert_allclose(pgm.match_psfs(g["psf2"], g["psf1"]), g["k12"], rtol=0, atol=1e-12)
+    assert_allclose(pgm.match_psfs(g["psf1"], g["psf2"]), g["k21"], rtol=0, atol=1e-9 * np.abs(g["k21"]).max())
+    assert_allclose(pgm.convolve(g["img"], g["ker"], axes=(1, 2)), g["conv"], rtol=0, atol=1e-12)
+    # narrow<->wide round trip (reference tests/test_fft.py:73-90)
+    assert_almost_equal(pgm.convolve(g["psf1"], g["k12"]), g["psf2"])
+
+
+def test_monotonic_fixture():
+    g = load_golden("monotonic")
+    for n in range(4):
+        shape = tuple(g["shape%d" % n]); c = tuple(g["center%d" % n])
+        w = pgm.radial_weights(shape, c)
+        assert_allclose(w, g["w%d" % n], rtol=0, atol=1e-14)
+        for tag, tol in (("f64", 1e-13), ("f32", 2e-6)):
+            for th in (0.0, 0.1):
+                X = g["x%d_%s_%g" % (n, tag, th)].copy()
+                pgm.prox_weighted_monotonic(X, c, th)
+                assert rel_err(X, g["y%d_%s_%g" % (n, tag, th)]) <= tol
+    for n in range(3):
+        shape = tuple(g["nshape%d" % n])
+        c = ((shape[0] - 1) // 2, (shape[1] - 1) // 2)
+        assert_array_equal(pgm.nearest_reference(shape, c), g["nref%d" % n])
+        X = g["nx%d" % n].copy()
+        pgm.prox_nearest_monotonic(X, c)
+        assert_array_equal(X, g["ny%d" % n])
+
+
+def test_sweep_order_independent_of_tie_order():
+    # any topological order of the "strictly closer" DAG gives identical values
+    rng = np.random.RandomState(0)
+    X = rng.rand(17, 19)
+    c = (6, 11)
+    a = X.copy(); pgm.prox_weighted_monotonic(a, c, 0.05)
+    order = pgm.radius_order(X.shape, c)
+    Y, Xc = np.mgrid[:17, :19]
+    d2 = ((Y - c[0]) ** 2 + (Xc - c[1]) ** 2).reshape(-1)
+    order2 = np.lexsort((-np.arange(d2.size), d2))   # reversed tie order
+    b = X.copy()
+    native.prox_weighted_monotonic(b.reshape(-1), pgm.radial_weights(X.shape, c),
+                                   pgm.neighbour_offsets(19), order2[1:], 0.05)
+    assert_array_equal(a, b)
+
+
+def test_measure_fixture():
+    g = load_golden("measure")
+    psf = g["psf"]
+    assert_allclose(pgm.default_centroid_weight(), psf, rtol=0, atol=1e-15)
+    for n in range(int(g["n"])):
+        m = g["m%d" % n]; c = tuple(g["c%d" % n])
+        mp = pgm.max_pixel(m, c)
+        assert_array_equal(mp, g["maxpix%d" % n])
+        nc, sh = pgm.psf_weighted_centroid(m, psf, mp)
+        assert_array_equal(nc, g["cen%d" % n])
+        assert_allclose(sh, g["shift%d" % n], rtol=0, atol=1e-13)
+        m32 = m.astype(np.float32)
+        nc, sh = pgm.psf_weighted_centroid(m32, psf, pgm.max_pixel(m32, c))
+        assert_array_equal(nc, g["cen32_%d" % n])
+        assert_allclose(sh, g["shift32_%d" % n], rtol=0, atol=1e-7)
+
+
+def test_symmetry_fixture():
+    g = load_golden("symmetry")
+    for n in range(int(g["n"])):
+        X = g["x%d" % n]; c = tuple(g["center%d" % n]); sh = g["shift%d" % n]
+        for alg in ("kspace", "soft", "sdss"):
+            for fill, ftag in ((None, "nofill"), (0.0, "fill")):
+                Y = X.copy()
+                pgm.prox_symmetry(Y, c, alg, fill, sh, .5)
+                assert_allclose(Y, g["y%d_%s_%s" % (n, alg, ftag)], rtol=0, atol=1e-13)
+        Y = X.copy(); pgm.prox_symmetry(Y, c, "kspace", None, np.zeros(2))
+        assert_allclose(Y, g["y%d_zero" % n], rtol=0, atol=1e-14)
+        Y = X.copy(); pgm.prox_symmetry(Y, c, "kspace", None, None)
+        assert_allclose(Y, g["y%d_none" % n], rtol=0, atol=1e-14)
+    assert_allclose(pgm.kspace_symmetry(g["kx"], (0.3, -0.45)), g["ky"], rtol=0, atol=1e-13)
+    assert_allclose(pgm.kspace_symmetry(g["kx2"], (-0.2, 0.15)), g["ky2"], rtol=0, atol=1e-13)
+
+
+def test_grad_fixture():
+    g = load_golden("grad")
+    seds = list(g["seds"]); morphs = list(g["morphs"])
+    diff = pgm.match_psfs(g["opsf"], g["tpsf"])
+    assert_allclose(diff, g["diff_psf"], rtol=0, atol=1e-12)
+    for tag, dk, w in (("nopsf", None, 1), ("nopsf_w", None, g["weights"]),
+                       ("psf", diff, 1), ("psf_w", diff, g["weights"])):
+        loss, gs, gm = pgm.loss_and_gradients(seds, morphs, g["images"], w, dk)
+        assert abs(loss - g["loss_" + tag]) <= 1e-12 * abs(g["loss_" + tag])
+        assert_allclose(np.array(gs), g["gsed_" + tag], rtol=1e-11, atol=1e-11)
+        assert_allclose(np.array(gm), g["gmorph_" + tag], rtol=1e-11, atol=1e-11)
+        model = pgm.scene_model(seds, morphs, g["images"].shape, np.float64)
+        assert_allclose(pgm.render(model, dk), g["render_" + tag], rtol=0, atol=1e-12)
+        L = pgm.lipschitz(seds, morphs)
+        assert_allclose(L, g["L_exact_" + tag], rtol=1e-12)
+        L = pgm.lipschitz(seds, morphs, approximate=True)
+        assert_allclose(L, g["L_approx_" + tag], rtol=1e-12)
+
+
+def test_gradient_matches_finite_differences():
+    g = load_golden("grad")
+    seds = [s.copy() for s in g["seds"]]; morphs = [m.copy() for m in g["morphs"]]
+    diff = pgm.match_psfs(g["opsf"], g["tpsf"])
+    w = g["weights"]
+    loss, gs, gm = pgm.loss_and_gradients(seds, morphs, g["images"], w, diff)
+    eps = 1e-6
+    for (k, idx) in ((0, (3, 4)), (1, (10, 20)), (1, (0, 0))):
+        mp = [m.copy() for m in morphs]; mp[k][idx] += eps
+        mm = [m.copy() for m in morphs]; mm[k][idx] -= eps
+        fd = (pgm.loss_and_gradients(seds, mp, g["images"], w, diff)[0] -
+              pgm.loss_and_gradients(seds, mm, g["images"], w, diff)[0]) / (2 * eps)
+        assert abs(fd - gm[k][idx]) <= 1e-6 * max(1, abs(fd))
+    for (k, b) in ((0, 1), (1, 2)):
+        sp = [s.copy() for s in seds]; sp[k][b] += eps
+        sm = [s.copy() for s in seds]; sm[k][b] -= eps
+        fd = (pgm.loss_and_gradients(sp, morphs, g["images"], w, diff)[0] -
+              pgm.loss_and_gradients(sm, morphs, g["images"], w, diff)[0]) / (2 * eps)
+        assert abs(fd - gs[k][b]) <= 1e-6 * max(1, abs(fd))
+
+
+def test_update_fixture():
+    g = load_golden("update")
+    bbox = tuple(int(v) for v in g["bbox"]); c = tuple(int(v) for v in g["center"])
+    m = g["morph"].copy(); pgm.update_monotonic(m, c, bbox=bbox)
+    assert_allclose(m, g["mono_bbox"], rtol=0, atol=1e-14)
+    m = g["morph"].copy(); pgm.update_symmetric(m, c, shift=np.array((0.2, -0.1)), bbox=bbox)
+    assert_allclose(m, g["sym_bbox"], rtol=0, atol=1e-13)
+    m = g["morph"].copy(); pgm.prox_hard(m, 1 / 2., .5)
+    assert_array_equal(m, g["l0"])
+    m = g["morph"].copy(); pgm.prox_soft(m, 1 / 2., .5)
+    assert_allclose(m, g["l1"], rtol=0, atol=1e-16)
+
+
+def _hsc_scene(g, tag, dt):
+    # config-1 inputs are a committed copy of the reference's data file (data, not code)
+    d = load_golden("hsc_inputs")
+    images = d["images"].astype(dt)
+    scene = pgm.make_extended_scene(images, g["pixels"], np.ones(5) * 0.1,
+                                    obs_psfs=g["obs_psfs"].astype(dt),
+                                    frame_psf=g["model_psf"].astype(dt))
+    return scene
+
+
+def _restart(scene, g, pre, tag=""):
+    """Continue from the reference's own post-constructor state (sed, morph, centre, shift),
+    so that the trajectory comparison is not polluted by 1e-16-level differences of the
+    (separately tested) initialisation."""
+    return pgm.scene_from_state(scene.images, g[pre + "init_sed" + tag], g[pre + "init_morph" + tag],
+                                g[pre + "init_center" + tag], g[pre + "init_shift" + tag],
+                                diff_kernel=scene.diff_kernel,
+                                centroid_weight=scene.sources[0].centroid_weight)
+
+
+@pytest.mark.parametrize("tag,dt,tol", [("f64", np.float64, 1e-9), ("f32", np.float32, 2e-5)])
+def test_fit_hsc_fixture(tag, dt, tol):
+    """BASELINE config 1: init + 50 PGM iterations on hsc_cosmos_35 rows 0-1."""
+    g = load_golden("fit_hsc")
+    scene = _hsc_scene(g, tag, dt)
+    assert rel_err(scene.diff_kernel, g["diff_kernel"]) <= (1e-12 if tag == "f64" else 1e-5)
+    assert rel_err(np.array([s.sed for s in scene.sources]), g["init_sed_" + tag]) <= tol
+    assert rel_err(np.array([s.morph for s in scene.sources]), g["init_morph_" + tag]) <= tol
+    assert_array_equal(np.array([s.center for s in scene.sources]), g["init_center_" + tag])
+    assert_allclose(np.array([s.shift for s in scene.sources]), g["init_shift_" + tag], rtol=0, atol=1e-6)
+    scene = _restart(scene, g, "", "_" + tag)
+    pgm.fit(scene, 50, e_rel=0)
+    assert_array_equal(np.array([s.center for s in scene.sources]), g["center_" + tag])
+    assert rel_err(np.array(scene.mse), g["mse_" + tag]) <= tol
+    assert rel_err(np.array([s.sed for s in scene.sources]), g["sed_" + tag]) <= tol
+    assert rel_err(np.array([s.morph for s in scene.sources]), g["morph_" + tag]) <= tol
+    assert_allclose(np.array([s.shift for s in scene.sources]), g["shift_" + tag], rtol=0,
+                    atol=1e-9 if tag == "f64" else 1e-5)
+    assert_array_equal(np.array([s.flags for s in scene.sources]), g["flags_" + tag])
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+@pytest.mark.parametrize("tag,dt,tol", [("f64", np.float64, 1e-9), ("f32", np.float32, 2e-5)])
+def test_fit_synth_fixture(idx, tag, dt, tol):
+    """BASELINE config 2 shaped scenes: init, 1 iteration, 30 iterations."""
+    g = load_golden("fit_synth")
+    pre = "s%d_%s_" % (idx, tag)
+    scn = synth.make_scene(idx)
+    images = scn["images"].astype(dt)
+    scene = pgm.make_extended_scene(images, scn["centers"], np.ones(5) * 0.1)
+    assert rel_err(np.array([s.morph for s in scene.sources]), g[pre + "init_morph"]) <= tol
+    assert rel_err(np.array([s.sed for s in scene.sources]), g[pre + "init_sed"]) <= tol
+    assert_array_equal(np.array([s.center for s in scene.sources]), g[pre + "init_center"])
+    assert_allclose(np.array([s.shift for s in scene.sources]), g[pre + "init_shift"], rtol=0, atol=1e-6)
+    scene = _restart(scene, g, pre)
+    pgm.fit(scene, 1, e_rel=0)
+    assert rel_err(np.array([s.morph for s in scene.sources]), g[pre + "it1_morph"]) <= tol
+    assert rel_err(np.array([s.sed for s in scene.sources]), g[pre + "it1_sed"]) <= tol
+    pgm.fit(scene, 29, e_rel=0)
+    assert_array_equal(np.array([s.center for s in scene.sources]), g[pre + "center"])
+    assert rel_err(np.array(scene.mse), g[pre + "mse"]) <= tol
+    assert rel_err(np.array([s.sed for s in scene.sources]), g[pre + "sed"]) <= tol
+    assert rel_err(np.array([s.morph for s in scene.sources]), g[pre + "morph"]) <= tol
+    assert_array_equal(np.array([s.flags for s in scene.sources]), g[pre + "flags"])
+
+
+def test_fit_synth_ragged_and_approx():
+    g = load_golden("fit_synth")
+    scn = synth.make_scene(0)
+    scene0 = pgm.make_extended_scene(scn["images"], scn["centers"], np.ones(5) * 0.1)
+    scene = _restart(scene0, g, "s0_f32_")
+    pgm.fit(scene, 200, e_rel=1e-2)
+    assert scene.it == int(g["s0_f32_erel_it"])
+    assert rel_err(np.array([s.morph for s in scene.sources]), g["s0_f32_erel_morph"]) <= 2e-5
+    assert_array_equal(np.array([s.flags for s in scene.sources]), g["s0_f32_erel_flags"])
+    scene = _restart(scene0, g, "s0_f32_")
+    pgm.fit(scene, 30, e_rel=0, approximate_L=True)
+    assert rel_err(np.array(scene.mse), g["s0_f32_approx_mse"]) <= 2e-5
+    assert rel_err(np.array([s.morph for s in scene.sources]), g["s0_f32_approx_morph"]) <= 2e-5
