@@ -1,0 +1,224 @@
+/*
+ * scarlet_hip.h -- C ABI of the MI355X (gfx950) proximal-gradient deblending engine.
+ *
+ * Drop-in boundary for the hot path of scarlet's Blend.fit().
+ * The reference's only native boundary is the pybind11 module built from
+ * scarlet/operators_pybind11.cc; everything else on the path is numpy called from
+ * Python.  This header therefore has three groups:
+ *
+ *   1. host-pointer drop-ins for the three pybind11 functions (same argument
+ *      meaning, caller-owned host buffers mutated in place),
+ *   2. batched device-pointer operators -- one call per (reference function x batch
+ *      of arrays): these are what scarlet_amd/operator.py, update.py, measurement.py
+ *      bind, i.e. what a maintainer would call from the reference's operator.py /
+ *      update.py / measurement.py in place of the numpy code,
+ *   3. the batched Blend.fit() engine (state struct + iteration driver).
+ *
+ * Conventions: plain C types only.  Device pointers are HIP device pointers into
+ * memory owned by the caller (PyTorch-ROCm tensors in the Python host layer).  All
+ * device arrays are C-contiguous float32 unless stated otherwise.  `stream` is a
+ * hipStream_t passed as void*; every device entry point is asynchronous on it and
+ * allocates nothing.  Return value: 0 = ok, negative = SCARLET_E_* (argument errors
+ * are detected on the host before any launch).  No global state except the
+ * constant table of fast FFT lengths initialised on first use.
+ */
+#ifndef SCARLET_HIP_H
+#define SCARLET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCARLET_OK            0
+#define SCARLET_E_ARG        -1   /* bad shape / null pointer / unsupported option  */
+#define SCARLET_E_TOO_LARGE  -2   /* H*W tile does not fit the 160 KiB LDS budget   */
+#define SCARLET_E_HIP        -3   /* a HIP runtime call failed (see scarlet_last_error) */
+#define SCARLET_E_NOTIMPL    -4   /* reference raises NotImplementedError here      */
+
+/* BlendFlag bits -- scarlet/component.py:13-36 */
+#define SCARLET_FLAG_SED_NOT_CONVERGED   1
+#define SCARLET_FLAG_MORPH_NOT_CONVERGED 2
+#define SCARLET_FLAG_EDGE_PIXELS         4
+#define SCARLET_FLAG_NO_VALID_PIXELS     8
+
+/* per-scene status bits written by the engine (0 = healthy) */
+#define SCARLET_STATUS_CENTER_AT_EDGE    1  /* max_pixel window start < 0: the reference
+                                               would raise (measurement.py:24-29)          */
+#define SCARLET_STATUS_NONFINITE         2  /* NaN/Inf met in centroid or normalisation   */
+
+/* symmetry algorithms -- scarlet/operator.py:291-350 */
+#define SCARLET_SYM_KSPACE 0
+#define SCARLET_SYM_SOFT   1
+#define SCARLET_SYM_SDSS   2
+
+/* normalisation types -- scarlet/update.py:35-68 */
+#define SCARLET_NORM_SED       0
+#define SCARLET_NORM_MORPH     1
+#define SCARLET_NORM_MORPH_MAX 2
+
+const char *scarlet_version(void);
+const char *scarlet_last_error(void);
+/* 5-smooth fast FFT length (scipy.fftpack.next_fast_len as used by fft.py:99) */
+int scarlet_next_fast_len(int n);
+
+/* ------------------------------------------------------------------------------
+ * 1. Host-pointer drop-ins for scarlet/operators_pybind11.cc
+ * ---------------------------------------------------------------------------- */
+
+/* replaces prox_monotonic (operators_pybind11.cc:11-25): x[d] = min(x[d],
+ * x[ref_idx[d]]*(1-thresh)) for d in dist_idx order.  x: n doubles, mutated. */
+int scarlet_host_prox_monotonic_f64(double *x, int n, const int *ref_idx,
+                                    const int *dist_idx, int n_dist, double thresh);
+
+/* replaces prox_weighted_monotonic<float> / <double> (operators_pybind11.cc:27-50,
+ * 82-85).  weights: row-major [8][n] (numpy order), offsets: 8 flat neighbour
+ * offsets, dist_idx: radius-sorted pixel indices without the peak.  x mutated. */
+int scarlet_host_prox_weighted_monotonic_f32(float *x, int n, const float *weights,
+                                             const int *offsets, const int *dist_idx,
+                                             int n_dist, float thresh);
+int scarlet_host_prox_weighted_monotonic_f64(double *x, int n, const double *weights,
+                                             const int *offsets, const int *dist_idx,
+                                             int n_dist, double thresh);
+
+/* replaces apply_filter<float> (operators_pybind11.cc:53-70): result = sum_n
+ * values[n] * shifted block of image. */
+int scarlet_host_apply_filter_f32(const float *image, int H, int W, const float *values,
+                                  const int *y_start, const int *y_end, const int *x_start,
+                                  const int *x_end, int n, float *result);
+
+/* ------------------------------------------------------------------------------
+ * 2. Batched device operators (n arrays of H x W, row stride W, array stride H*W)
+ * ---------------------------------------------------------------------------- */
+
+/* update.monotonic default path: operator.prox_strict_monotonic(use_nearest=False)
+ * -> operators_pybind11.prox_weighted_monotonic (update.py:106-156, operator.py:81-122,
+ * 540-621).  The radial cos-weights and the sweep order are generated on the fly from
+ * `centers` (device int32 [n][2] = (y, x)); no weight table, no argsort.  In place. */
+int scarlet_prox_weighted_monotonic(float *x, int n, int H, int W, const int32_t *centers,
+                                    float thresh, void *stream);
+
+/* operator.prox_strict_monotonic(use_nearest=True) (operator.py:104-113): reference pixel
+ * = first neighbour with the largest cos-weight.  thresh must be 0 (ValueError in the
+ * reference otherwise -> SCARLET_E_ARG). */
+int scarlet_prox_nearest_monotonic(float *x, int n, int H, int W, const int32_t *centers,
+                                   float thresh, void *stream);
+
+/* operator.prox_uncentered_symmetry (operator.py:291-350) incl. uncentered_operator
+ * window selection (:175-228), prox_soft_symmetry (:242-251), prox_sdss_symmetry
+ * (:231-239), prox_kspace_symmetry (:253-288, evaluated as the equivalent real-space
+ * Dirichlet-kernel operator).  shifts: device float64 [n][2] = (dy, dx)
+ * or NULL; `algorithm` is applied as given (the caller resolves the reference's
+ * "kspace -> soft when shift is None/0" rule, operator.py:337-339).  use_fill != 0
+ * writes `fill` outside the symmetric window.  In place. */
+int scarlet_prox_symmetry(float *x, int n, int H, int W, const int32_t *centers,
+                          const double *shifts, int algorithm, float strength,
+                          int use_fill, float fill, void *stream);
+
+/* measurement.max_pixel (measurement.py:3-29): 5x5 window argmax, first hit row-major.
+ * centers_io updated in place; status (device int32 [n] or NULL) gets
+ * SCARLET_STATUS_CENTER_AT_EDGE or-ed in when the reference would have failed. */
+int scarlet_max_pixel(const float *x, int n, int H, int W, int32_t *centers_io,
+                      int32_t *status, void *stream);
+
+/* measurement.psf_weighted_centroid (measurement.py:32-94).  psf: device float64 [P][P]
+ * (P odd).  centers_io updated, shifts_out float64 [n][2]. */
+int scarlet_psf_weighted_centroid(const float *x, int n, int H, int W, const double *psf,
+                                  int P, int32_t *centers_io, double *shifts_out,
+                                  int32_t *status, void *stream);
+
+/* proxmin prox_plus / prox_hard / prox_soft as bound by update.py:13-32,71-82.
+ * `count` contiguous floats; step per call (thresh*step is the cut). */
+int scarlet_prox_plus(float *x, int64_t count, void *stream);
+int scarlet_prox_hard(float *x, int64_t count, float thresh_times_step, void *stream);
+int scarlet_prox_soft(float *x, int64_t count, float thresh_times_step, void *stream);
+
+/* update.normalized (update.py:35-68) for n components: sed [n][B], morph [n][H*W]. */
+int scarlet_normalize(float *sed, float *morph, int n, int B, int HW, int type, void *stream);
+
+/* apply_filter on device (operators_pybind11.cc:53-70), one image. */
+int scarlet_apply_filter(const float *image, int H, int W, const float *values,
+                         const int32_t *y_start, const int32_t *y_end, const int32_t *x_start,
+                         const int32_t *x_end, int n, float *result, void *stream);
+
+/* ------------------------------------------------------------------------------
+ * 3. Batched Blend.fit() engine (blend.py:65-223, source.py:402-440)
+ * ---------------------------------------------------------------------------- */
+
+typedef struct scarlet_batch {
+    /* shapes: S scenes, K components per scene, B bands, H x W pixels */
+    int32_t S, K, B, H, W;
+    /* data (read only) */
+    const float *images;      /* [S][B][H][W]                                          */
+    const float *weights;     /* [S][B][H][W] or NULL -> scalar `weight_scalar`
+                                 (observation.py:148-151)                              */
+    float weight_scalar;
+    /* factors, ping-pong: buffer `cur` holds the current values, the other one the
+       values of the previous iteration (_last_sed/_last_morph, blend.py:179-182)      */
+    float *sed[2];            /* [S][K][B]                                             */
+    float *morph[2];          /* [S][K][H][W]                                          */
+    int32_t *cur;             /* [S] device: index of each scene's current buffer; a scene's
+                                 index flips once per iteration it takes part in        */
+    /* per component */
+    int32_t *centers;         /* [S][K][2] pixel_center (y, x)                         */
+    double *shifts;           /* [S][K][2] sub-pixel shift from the last centroid      */
+    int32_t *flags;           /* [S][K]    BlendFlag bits                              */
+    const uint8_t *fix_sed;   /* [S][K] or NULL (component.py:111-112)                 */
+    const uint8_t *fix_morph; /* [S][K] or NULL                                        */
+    /* per scene */
+    double *lipschitz;        /* [S][2]  (L_sed, L_morph) of the last iteration        */
+    double *mse;              /* [S][mse_capacity] loss before each step (blend.py:138) */
+    int32_t mse_capacity;
+    int32_t *it;              /* [S] = len(mse)                                        */
+    int32_t *active;          /* [S] 1 while the scene has not met e_rel in this fit()  */
+    int32_t *status;          /* [S] SCARLET_STATUS_* bits                             */
+    /* constraint pipeline of PointSource/ExtendedSource.update (source.py:402-440)    */
+    int32_t symmetric, monotonic;
+    float l0_thresh, l1_thresh;  /* < 0 -> off; else update.sparse_l0/l1 before positive */
+    const double *centroid_psf;  /* [P][P] float64 centroid weight (source.py:483-490) */
+    int32_t centroid_P;
+    /* workspace owned by the caller: scarlet_batch_workspace_bytes() bytes            */
+    void *workspace;
+} scarlet_batch;
+
+/* bytes of device workspace needed for `b` (depends on S, K, B, H, W only) */
+int64_t scarlet_batch_workspace_bytes(const scarlet_batch *b);
+
+/* Run up to `max_iter` proximal-gradient iterations on every active scene
+ * (Blend.fit, blend.py:65-102).  Per iteration and scene: loss + analytic gradient
+ * (_backward/_loss, :105-139), Lipschitz constants (_set_lipschitz, :186-223, exact or
+ * approximate), gradient step (:87-96), per-component constraint pipeline
+ * (source.py:402-440), convergence flags (_check_convergence, :141-184).  A scene that
+ * converges stops iterating (its `active` becomes 0), exactly like the reference's
+ * `break`.  `check_every` > 0: every that many iterations the active flags are copied
+ * to the host (one stream sync) to stop early when every scene is done; 0: never sync.
+ * Returns the number of iterations launched (>= 0) or an error. */
+int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int approximate_L,
+                int check_every, void *stream);
+
+/* Single phases, exposed for tests and for Python-overridden update() methods:        */
+/* _backward + _set_lipschitz + gradient step (blend.py:81-96): reads buffer cur, writes
+ * the stepped factors into buffer 1-cur; cur/it are NOT advanced yet                   */
+int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *stream);
+/* the built-in constraint pipeline (source.py:402-440).  in_iteration=1: on buffer 1-cur
+ * (between backward_step and check_convergence); 0: on buffer cur with it=0 semantics,
+ * as the source constructors do (source.py:400,492)                                    */
+int scarlet_source_update(scarlet_batch *b, int in_iteration, void *stream);
+/* _check_convergence (blend.py:141-184) on buffer 1-cur vs cur, then closes the
+ * iteration: it += 1, cur flips, active cleared for converged scenes                   */
+int scarlet_check_convergence(scarlet_batch *b, double e_rel, void *stream);
+
+/* ExtendedSource initialisation on device (source.py:139-180, rank f1 of SURVEY 8f):
+ * per component: pixel SED (optionally PSF-corrected by the caller through sed_scale
+ * [B] or NULL), detection coadd, sdss symmetry, thresh=0.1 weighted monotone sweep,
+ * cut at bg_cutoff, divide by the centre pixel.  Writes sed/morph of buffer b->cur,
+ * flags (NO_VALID_PIXELS when nothing is above the cut), then runs the constraint
+ * pipeline once with it=0 as the constructor does (source.py:492).  bg_rms: host [B]. */
+int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host, float thresh,
+                          const float *sed_scale_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCARLET_HIP_H */

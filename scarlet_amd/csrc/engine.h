@@ -1,0 +1,430 @@
+// engine.h -- kernels of the batched Blend.fit() iteration.
+//
+// HBM layout (DESIGN.md "Data layout"): scene-major, images [S][B][H][W], morph
+// [S][K][H][W], sed [S][K][B]; factors are ping-pong buffered so that the buffer not
+// being written always holds the previous iteration (the reference's _last_* copies).
+//
+// One iteration =
+//   k_grad         grid (T, S)  : stream images + morphs once, per-tile partial sums of
+//                                 loss, d loss/d sed, morph Gram (f64)           [a1-a5]
+//   k_step         grid (T, S)  : reduce partials, Lipschitz constants (Jacobi eigen-
+//                                 solve), SED step, recompute G and step the morphs [a6, a7]
+//   k_source_update grid (S*K)  : constraint pipeline in LDS (prox_ops.h)        [a8-a17]
+//   k_converge     grid (S/256) : flags / active / it bookkeeping                [a18]
+#pragma once
+#include "common.h"
+#include "prox_ops.h"
+
+#define SC_TILE_PIX 4096          // pixels per (scene, tile) workgroup in k_grad / k_step
+#define SC_KMAX 8
+#define SC_BMAX 8
+
+__host__ __device__ inline int n_partials(int K, int B) { return 1 + K * B + K * (K + 1) / 2; }
+
+struct GradArgs {
+    int S, K, B, HW, T;
+    const float *images, *weights;
+    float weight_scalar;
+    float *sed[2], *morph[2];     // ping-pong factor buffers
+    const int *cur;               // [S] index of the current buffer of each scene
+    const uint8_t *fix_sed, *fix_morph;
+    double *partials;             // [S][T][P]
+    double *lipschitz, *mse;
+    int mse_capacity;
+    int *it;
+    const int *active;
+    int approximate_L;
+};
+
+// ------------------------------------------------------------------------------------
+// k_grad: per pixel p of the tile
+//   model_b = sum_k sed[k][b] morph[k][p]           (a1, a2; render is the identity, a3)
+//   d_b = w (model_b - image_b), loss += d_b^2 / 2   (a4)
+//   G_b = w d_b ; dsed[k][b] += G_b morph[k][p]      (a5)
+//   gram[k][k'] += morph[k][p] morph[k'][p]          (a6, S S^T)
+// Loads: lane-contiguous float per (band | component) plane -> fully coalesced.
+template <int KM, int BM>
+__global__ __launch_bounds__(SC_BLOCK) void k_grad(GradArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.HW;
+    __shared__ float sed_s[KM * BM];
+    __shared__ double red[SC_NWAVES][1 + KM * BM + KM * (KM + 1) / 2];
+    const int c0 = a.cur[s];
+    const float *sed_in = a.sed[c0];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
+        sed_s[(i / B) * BM + (i % B)] = sed_in[(size_t)s * K * B + i];
+    __syncthreads();
+    float sed[KM][BM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b) sed[k][b] = (k < K && b < B) ? sed_s[k * BM + b] : 0.f;
+
+    double loss = 0;
+    float dsed[KM][BM];
+    float gram[KM * (KM + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b) dsed[k][b] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KM * (KM + 1) / 2; ++i) gram[i] = 0.f;
+
+    const float *img = a.images + (size_t)s * B * HW;
+    const float *wgt = a.weights ? a.weights + (size_t)s * B * HW : nullptr;
+    const float *mor = a.morph[c0] + (size_t)s * K * HW;
+    const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
+        float m[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) m[k] = k < K ? mor[(size_t)k * HW + p] : 0.f;
+#pragma unroll
+        for (int b = 0; b < BM; ++b) {
+            if (b < B) {
+                float model = 0.f;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) model += sed[k][b] * m[k];
+                const float w = wgt ? wgt[(size_t)b * HW + p] : a.weight_scalar;
+                const float d = w * (model - img[(size_t)b * HW + p]);
+                loss += (double)d * (double)d;
+                const float g = w * d;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) dsed[k][b] += g * m[k];
+            }
+        }
+        int gi = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < KM; ++k2) gram[gi++] += m[k] * m[k2];
+    }
+    // block reduction (f64) -> partials[s][tile][:]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double v = wave_sum(0.5 * loss);
+    if (lane == 0) red[wid][0] = v;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b) {
+            if (k < K && b < B) {
+                v = wave_sum((double)dsed[k][b]);
+                if (lane == 0) red[wid][1 + k * B + b] = v;
+            }
+        }
+    {
+        int gi = 0, go = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < KM; ++k2) {
+                if (k < K && k2 < K) {
+                    v = wave_sum((double)gram[gi]);
+                    if (lane == 0) red[wid][1 + K * B + go] = v;
+                    ++go;
+                }
+                ++gi;
+            }
+    }
+    __syncthreads();
+    const int P = n_partials(K, B);
+    double *out = a.partials + ((size_t)s * a.T + tile) * P;
+    for (int i = threadIdx.x; i < P; i += SC_BLOCK) {
+        double r = 0;
+#pragma unroll
+        for (int w = 0; w < SC_NWAVES; ++w) r += red[w][i];
+        out[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Largest eigenvalue of a symmetric n x n matrix (n <= 8), cyclic Jacobi in float64.
+// Replaces np.linalg.eigvals(...).max() of blend.py:216-218 (the matrices are Gram
+// matrices: real symmetric PSD, so the general solver's result is real).
+__device__ inline double jacobi_lambda_max(double *A, int n, int ld)
+{
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; ++i) {
+            diag += A[i * ld + i] * A[i * ld + i];
+            for (int j = i + 1; j < n; ++j) off += A[i * ld + j] * A[i * ld + j];
+        }
+        if (off <= 1e-30 * diag || off == 0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * ld + q];
+                if (apq == 0) continue;
+                const double theta = (A[q * ld + q] - A[p * ld + p]) / (2 * apq);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(tt * tt + 1), sn = tt * c;
+                for (int r = 0; r < n; ++r) {
+                    const double arp = A[r * ld + p], arq = A[r * ld + q];
+                    A[r * ld + p] = c * arp - sn * arq;
+                    A[r * ld + q] = sn * arp + c * arq;
+                }
+                for (int r = 0; r < n; ++r) {
+                    const double apr = A[p * ld + r], aqr = A[q * ld + r];
+                    A[p * ld + r] = c * apr - sn * aqr;
+                    A[q * ld + r] = sn * apr + c * aqr;
+                }
+            }
+    }
+    double l = A[0];
+    for (int i = 1; i < n; ++i) l = fmax(l, A[i * ld + i]);
+    return l;
+}
+
+// ------------------------------------------------------------------------------------
+// k_step: finish _backward (mse), _set_lipschitz, and the gradient step of Blend.fit.
+template <int KM, int BM>
+__global__ __launch_bounds__(SC_BLOCK) void k_step(GradArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.HW, P = n_partials(K, B);
+    __shared__ double tot[1 + KM * BM + KM * (KM + 1) / 2];
+    __shared__ double mat[KM * KM + BM * BM];
+    __shared__ float sed_s[KM * BM];
+    __shared__ float step_s[2];
+    for (int i = threadIdx.x; i < P; i += SC_BLOCK) {
+        double r = 0;
+        for (int t = 0; t < a.T; ++t) r += a.partials[((size_t)s * a.T + t) * P + i];
+        tot[i] = r;
+    }
+    const int c0 = a.cur[s];
+    const float *sed_in = a.sed[c0];
+    float *sed_out = a.sed[1 - c0];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
+        sed_s[(i / B) * BM + (i % B)] = sed_in[(size_t)s * K * B + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int it_new = a.it[s] + 1;                  // len(mse) after the append
+        const double loss = tot[0];
+        double L_sed, L_morph;
+        if (a.approximate_L) {
+            // blend.py:189-202: traces of the two Gram matrices, doubled if the loss rose
+            double LA = 0, LS = 0;
+            int go = 0;
+            for (int k = 0; k < K; ++k)
+                for (int k2 = k; k2 < K; ++k2) { if (k2 == k) LA += tot[1 + K * B + go]; ++go; }
+            for (int k = 0; k < K; ++k)
+                for (int b = 0; b < B; ++b) LS += (double)sed_s[k * BM + b] * sed_s[k * BM + b];
+            if (it_new > 1 && loss > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { LA *= 2; LS *= 2; }
+            L_sed = LA; L_morph = LS;
+        } else {
+            // blend.py:205-218: L_sed = lambda_max(S S^T), L_morph = lambda_max(A^T A)
+            double *G = mat, *ATA = mat + KM * KM;
+            int go = 0;
+            for (int k = 0; k < K; ++k)
+                for (int k2 = k; k2 < K; ++k2) {
+                    G[k * KM + k2] = G[k2 * KM + k] = tot[1 + K * B + go]; ++go;
+                }
+            for (int b = 0; b < B; ++b)
+                for (int b2 = 0; b2 < B; ++b2) {
+                    double r = 0;
+                    for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
+                    ATA[b * BM + b2] = r;
+                }
+            L_sed = jacobi_lambda_max(G, K, KM);
+            L_morph = jacobi_lambda_max(ATA, B, BM);
+        }
+        // frame dtype is float32: the reference's L and 1/L are float32 scalars
+        step_s[0] = 1.0f / (float)L_sed;
+        step_s[1] = 1.0f / (float)L_morph;
+        if (tile == 0) {
+            if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
+            a.lipschitz[2 * s] = L_sed;
+            a.lipschitz[2 * s + 1] = L_morph;
+        }
+    }
+    __syncthreads();
+    const float step_sed = step_s[0], step_morph = step_s[1];
+    // SED step (blend.py:91-93); tile 0 writes the new SEDs into the other buffer
+    if (tile == 0) {
+        for (int i = threadIdx.x; i < K * B; i += SC_BLOCK) {
+            const int k = i / B;
+            const float cur = sed_s[k * BM + (i % B)];
+            const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + k];
+            sed_out[(size_t)s * K * B + i] = fixed ? cur : cur - step_sed * (float)tot[1 + i];
+        }
+    }
+    // morphology step (blend.py:94-96): G recomputed from the streamed tiles
+    float sed[KM][BM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b) sed[k][b] = (k < K && b < B) ? sed_s[k * BM + b] : 0.f;
+    bool fixm[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) fixm[k] = (k < K) && a.fix_morph && a.fix_morph[(size_t)s * K + k];
+    const float *img = a.images + (size_t)s * B * HW;
+    const float *wgt = a.weights ? a.weights + (size_t)s * B * HW : nullptr;
+    const float *mor = a.morph[c0] + (size_t)s * K * HW;
+    float *mout = a.morph[1 - c0] + (size_t)s * K * HW;
+    const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
+        float m[KM], gm[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) { m[k] = k < K ? mor[(size_t)k * HW + p] : 0.f; gm[k] = 0.f; }
+#pragma unroll
+        for (int b = 0; b < BM; ++b) {
+            if (b < B) {
+                float model = 0.f;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) model += sed[k][b] * m[k];
+                const float w = wgt ? wgt[(size_t)b * HW + p] : a.weight_scalar;
+                const float g = w * (w * (model - img[(size_t)b * HW + p]));
+#pragma unroll
+                for (int k = 0; k < KM; ++k) gm[k] += sed[k][b] * g;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < K) mout[(size_t)k * HW + p] = fixm[k] ? m[k] : m[k] - step_morph * gm[k];
+    }
+    // a.it[s] is advanced by k_converge (every tile of this launch reads the old value)
+}
+
+// ------------------------------------------------------------------------------------
+// k_source_update: PointSource.update / ExtendedSource.update (source.py:402-440) for one
+// component per workgroup, entirely in LDS.
+struct UpdateArgs {
+    int S, K, B, H, W;
+    float *sed[2], *morph[2];         // ping-pong factor buffers
+    const int *cur;                   // [S]
+    int in_iteration;                 // 1: called between k_step and k_converge -> operate on
+                                      //    buffer 1-cur (just written), previous = buffer cur
+                                      // 0: standalone -> operate on buffer cur, no a18 sums
+    int *centers; double *shifts;
+    const double *lipschitz;
+    const int *it; const int *active;
+    int *status;
+    int symmetric, monotonic;
+    float l0_thresh, l1_thresh;
+    const double *centroid_psf; int centroid_P;
+    double *conv;                     // [S][K][4]: d2_sed, n2_sed, d2_morph, n2_morph
+    int force_it0;                    // 1: constructor call (it = 0, ignore `active`)
+};
+
+__global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int c = blockIdx.x, s = c / a.K;
+    if (!a.force_it0 && !a.active[s]) return;
+    const int H = a.H, W = a.W, HW = H * W, B = a.B;
+    Tile t; t.H = H; t.W = W; t.LW = tile_stride(W); t.m = lds;
+    float *scr = lds + H * t.LW;
+    const int hp = round16(H), wp = round16(W);
+    float *av = scr + hp * scratch_stride(wp);
+    float *bv = av + 2 * hp, *cv = bv + 2 * wp, *zv = cv + 2 * wp;
+    __shared__ double red[SC_NWAVES];
+    __shared__ float redf[SC_NWAVES];
+    __shared__ int ctr[2];
+    __shared__ double shf[2];
+    __shared__ int stat;
+
+    const int c0 = a.cur[s];
+    const int wbuf = a.in_iteration ? 1 - c0 : c0;
+    float *gm = a.morph[wbuf] + (size_t)c * HW;
+    for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
+        const int y = i / W, x = i - y * W;
+        t.m[y * t.LW + x] = gm[i];
+    }
+    if (threadIdx.x == 0) stat = 0;
+    __syncthreads();
+    const int it = a.force_it0 ? 0 : a.it[s] + (a.in_iteration ? 1 : 0);   // len(mse)
+    int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
+
+    max_pixel_tile(t, cy, cx, ctr, &stat);                         // source.py:414
+    cy = ctr[0]; cx = ctr[1];
+    if (a.symmetric) {
+        double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
+        if (it % 5 == 0) {                                          // source.py:428-429
+            __syncthreads();
+            centroid_tile(t, a.centroid_psf, a.centroid_P, cy, cx, red, ctr, shf, &stat);
+            cy = ctr[0]; cx = ctr[1]; dy = shf[0]; dx = shf[1];
+            if (threadIdx.x == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
+        }
+        // update.symmetric(algorithm="kspace") (source.py:432): shift None -> soft, s=1
+        const bool none = (dy != dy);
+        symmetry_tile(t, cy, cx, none ? SCARLET_SYM_SOFT : SCARLET_SYM_KSPACE, 1.0f, dy, dx,
+                      false, 0.f, scr, av, bv, cv, zv);
+    }
+    if (a.monotonic) monotonic_tile<false, float>(t, cy, cx, 0.f);         // source.py:436
+    if (threadIdx.x == 0) { a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
+
+    // sparse_l0 / sparse_l1 (update.py:71-82; config 5), positive (update.py:27-32),
+    // normalized('morph_max') (update.py:62-65)
+    const float step_morph = 1.0f / (float)a.lipschitz[2 * s + 1];
+    float vmax = -INFINITY;
+    bool anynan = false;
+    for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
+        const int y = i / W, x = i - y * W;
+        float v = t.m[y * t.LW + x];
+        if (a.l0_thresh >= 0.f && fabsf(v) < a.l0_thresh * step_morph) v = 0.f;
+        if (a.l1_thresh >= 0.f) {
+            const float mag = fabsf(v) - a.l1_thresh * step_morph;
+            v = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
+        }
+        if (v < 0.f) v = 0.f;
+        t.m[y * t.LW + x] = v;
+        anynan |= (v != v);
+        vmax = fmaxf(vmax, v);
+    }
+    const float norm = block_max_nan(vmax, anynan, redf);
+    if (threadIdx.x == 0 && (!(norm > 0.f) || isinf(norm))) stat |= SCARLET_STATUS_NONFINITE;
+    const float *gl = a.in_iteration ? a.morph[c0] + (size_t)c * HW : nullptr;
+    double d2 = 0, n2 = 0;
+    for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
+        const int y = i / W, x = i - y * W;
+        const float v = t.m[y * t.LW + x] / norm;
+        gm[i] = v;
+        if (gl) { const float d = gl[i] - v; d2 += (double)(d * d); }
+        n2 += (double)(v * v);
+    }
+    d2 = block_sum(d2, red);
+    n2 = block_sum(n2, red);
+    if (threadIdx.x == 0) {
+        float *gs = a.sed[wbuf] + (size_t)c * B;
+        const float *gsl = a.in_iteration ? a.sed[c0] + (size_t)c * B : nullptr;
+        double d2s = 0, n2s = 0;
+        for (int b = 0; b < B; ++b) {
+            float v = gs[b];
+            if (v < 0.f) v = 0.f;
+            v = v * norm;
+            gs[b] = v;
+            if (gsl) { const float d = gsl[b] - v; d2s += (double)(d * d); }
+            n2s += (double)(v * v);
+        }
+        a.conv[4 * c + 0] = d2s; a.conv[4 * c + 1] = n2s;
+        a.conv[4 * c + 2] = d2;  a.conv[4 * c + 3] = n2;
+        if (stat) atomicOr(&a.status[s], stat);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_converge: Blend._check_convergence (blend.py:141-184), one thread per scene.
+// Also closes the iteration for the scene: it += 1 (len(mse)), cur flips.
+__global__ void k_converge(int S, int K, const double *conv, int *flags, int *active,
+                           int *it, int *cur, double e_rel2)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S || !active[s]) return;
+    const int it_new = it[s] + 1;
+    it[s] = it_new;
+    cur[s] = 1 - cur[s];
+    if (it_new > 1) {
+        bool done = true;
+        for (int k = 0; k < K; ++k) {
+            const double *c = conv + 4 * ((size_t)s * K + k);
+            int f = flags[s * K + k];
+            if (c[0] <= e_rel2 * c[1]) f &= ~SCARLET_FLAG_SED_NOT_CONVERGED;
+            else { f |= SCARLET_FLAG_SED_NOT_CONVERGED; done = false; }
+            if (c[2] <= e_rel2 * c[3]) f &= ~SCARLET_FLAG_MORPH_NOT_CONVERGED;
+            else { f |= SCARLET_FLAG_MORPH_NOT_CONVERGED; done = false; }
+            flags[s * K + k] = f;
+        }
+        if (done) active[s] = 0;
+    }
+}
