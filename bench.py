@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Headline benchmark: proximal-gradient iterations/s on synthetic 5-band 64x64 scenes.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one PGM iteration (Blend.fit inner loop: loss gradient, Lipschitz step,
+constraint pipeline, convergence flags) over the whole resident batch of scenes.
+Workload at N=1: BASELINE.json's metric configuration -- 10 000 scenes of 5 bands x
+64 x 64 pixels with 4 sources each, no PSF (configs[3] on one GPU; configs[1] is the
+same scene shape at batch 1024).  For N>1 every rank owns its own 10 000 scenes
+(weak scaling; scenes are independent, no collective in the timed region) and the
+fitted SEDs are gathered to rank 0 over RCCL afterwards.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
+objects: "roofline" (dominant kernel, HIP-event timed on the launch stream) and
+"cpu_baseline" (the CPU oracle timed on this host's cores, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNEL_NAMES = ("k_grad", "k_step", "k_source_update", "k_converge")
+
+
+def algorithmic_bytes_per_scene_iteration(B, K, H, W):
+    """images read once, K morphs and SEDs read+written once."""
+    return 4 * H * W * (B + 2 * K) + 8 * K * B
+
+
+# ----------------------------------------------------------------------------- host workers
+def _gen_chunk(args):
+    from scarlet_amd import synth
+    start, count, kw = args
+    d = synth.make_batch(start, count, **kw)
+    return d["images"], d["centers"]
+
+
+def generate_scenes(start, count, pool, workers, **kw):
+    chunk = max(1, (count + 4 * workers - 1) // (4 * workers))
+    jobs = [(start + o, min(chunk, count - o), kw) for o in range(0, count, chunk)]
+    parts = pool.map(_gen_chunk, jobs) if pool is not None else [_gen_chunk(j) for j in jobs]
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
+def _cpu_worker(args):
+    """CPU oracle on a few scenes: returns (scene_iterations, seconds spent in fit)."""
+    from oracle import pgm
+    from scarlet_amd import synth
+    start, count, iters, kw = args
+    total, spent = 0, 0.0
+    for i in range(count):
+        scn = synth.make_scene(start + i, **kw)
+        sc = pgm.make_extended_scene(scn["images"], scn["centers"], np.ones(kw["B"]) * 0.1)
+        t0 = time.perf_counter()
+        pgm.fit(sc, iters, e_rel=0)
+        spent += time.perf_counter() - t0
+        total += iters
+    return total, spent
+
+
+def cpu_baseline(pool, workers, scenes_per_worker, iters, kw):
+    from oracle import build as obuild
+    obuild.build()
+    jobs = [(700000 + w * scenes_per_worker, scenes_per_worker, iters, kw) for w in range(workers)]
+    t0 = time.perf_counter()
+    res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    n = sum(r[0] for r in res)
+    # aggregate rate over the cores actually used (wall clock includes scene init)
+    busy = max(r[1] for r in res)
+    return dict(value=n / busy, unit="scene-iterations/s", cores=workers, kind="port",
+                sample="%d scenes x %d iterations of the same workload, CPU oracle (numpy + C sweep), "
+                       "%d processes, fit() time only (wall %.1f s)" % (workers * scenes_per_worker, iters, workers, wall))
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scenes", type=int, default=10000, help="scenes per GPU")
+    ap.add_argument("--bands", type=int, default=5)
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--sources", type=int, default=4)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-scenes", type=int, default=8, help="oracle scenes per host process")
+    ap.add_argument("--cpu-iters", type=int, default=25)
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus and world > 1:
+        print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+    B, H, W, K, S = args.bands, args.size, args.size, args.sources, args.scenes
+    kw = dict(B=B, H=H, W=W, K=K)
+
+    # ---- host-side work first, in forked workers, BEFORE this process touches the GPU
+    import multiprocessing as mp
+    share = max(1, (os.cpu_count() or 1) // max(1, world))
+    workers = max(1, min(16, share))
+    pool = mp.get_context("fork").Pool(workers)
+    cpu = None
+    try:
+        if rank == 0 and world == 1 and not args.no_cpu:
+            cpu = cpu_baseline(pool, workers, args.cpu_scenes, args.cpu_iters, kw)
+        t0 = time.perf_counter()
+        images, centers = generate_scenes(rank * S, S, pool, workers, **kw)
+        t_gen = time.perf_counter() - t0
+    finally:
+        pool.close()
+        pool.join()
+
+    # ---- device
+    import torch
+    from scarlet_amd import _lib, distributed
+    from scarlet_amd.batch import BlendBatch
+    _lib.require_gpu()
+    torch.cuda.set_device(local if world > 1 else 0)
+    distributed.init_from_env("nccl" if world > 1 else None)
+
+    batch = BlendBatch(images, centers, mse_capacity=args.steps + args.warmup + 1)
+    batch.init_extended(np.ones(B, dtype=np.float32) * 0.1)
+    torch.cuda.synchronize()
+    if args.warmup > 0:
+        batch.fit(args.warmup, e_rel=0, check_every=0)
+    torch.cuda.synchronize()
+    distributed.barrier()
+    _lib.check(_lib.lib.scarlet_profile_begin(args.steps))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    launched = batch.fit(args.steps, e_rel=0, check_every=0)
+    torch.cuda.synchronize()
+    distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    import ctypes
+    ms = (ctypes.c_double * 4)()
+    cnt = (ctypes.c_int64 * 4)()
+    _lib.check(_lib.lib.scarlet_profile_end(ms, cnt))
+    assert launched == args.steps
+    elapsed = distributed.max_over_ranks(elapsed)
+    n_active = int(batch.active.sum().item())
+    status_bad = int((batch.status != 0).sum().item())
+
+    # results travel back to rank 0 over RCCL (outside the timed region)
+    gathered = distributed.gather_scenes([batch.sed_current, batch.mse_buf[:, :args.steps + args.warmup]],
+                                         S * world)
+    if rank != 0:
+        return
+    total_scene_iters = float(S) * world * args.steps
+    value = total_scene_iters / elapsed
+    bytes_unit = algorithmic_bytes_per_scene_iteration(B, K, H, W)
+    dom = int(np.argmax([ms[i] for i in range(4)]))
+    avg_ms = ms[dom] / max(1, cnt[dom])
+    achieved = bytes_unit * S / (avg_ms * 1e-3) / 1e9
+    it_ms = 1e3 * elapsed / args.steps
+    mse = gathered[1].cpu().numpy()
+    out = {
+        "metric": "PGM iters/sec on 10k 5-band 64x64 scenes",
+        "value": value,
+        "unit": "scene-iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": it_ms,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%d scenes/GPU of %d-band %dx%d, %d sources/scene, no PSF "
+                               "(BASELINE configs[3] shape; configs[1] is the same at batch 1024)" % (S, B, H, W, K),
+                   "scenes_per_gpu": S, "bands": B, "height": H, "width": W, "sources": K,
+                   "parallelism": "scenes sharded, %d rank(s), no collective in the iteration" % world,
+                   "batch_iterations_per_s": args.steps / elapsed,
+                   "active_scenes_after_timed_region": n_active, "scenes_with_status": status_bad,
+                   "mean_loss_first_last": [float(mse[:, 0].mean()), float(mse[:, -1].mean())],
+                   "host_scene_generation_s": t_gen},
+        "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": args.traffic_bytes,
+                     "algorithmic_bytes_per_launch": bytes_unit * S, "avg_launch_ms": avg_ms,
+                     "per_kernel_avg_ms": {KERNEL_NAMES[i]: ms[i] / max(1, cnt[i]) for i in range(4)},
+                     "whole_iteration_frac": bytes_unit * S / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+        out["config"]["gpu_over_cpu_all_cores"] = value / cpu["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -209,6 +209,14 @@ int scarlet_source_update(scarlet_batch *b, int in_iteration, void *stream);
  * iteration: it += 1, cur flips, active cleared for converged scenes                   */
 int scarlet_check_convergence(scarlet_batch *b, double e_rel, void *stream);
 
+/* Per-kernel timing of scarlet_fit with hipEvents recorded on the launch stream (used by
+ * bench.py for the roofline line).  begin: allocate events for up to max_iterations
+ * iterations and start recording; end: synchronise, return per kernel class
+ * {0 grad, 1 step, 2 source_update, 3 converge} the summed milliseconds and launch
+ * counts, and stop recording. */
+int scarlet_profile_begin(int max_iterations);
+int scarlet_profile_end(double total_ms[4], int64_t launches[4]);
+
 /* ExtendedSource initialisation on device (source.py:139-180, rank f1 of SURVEY 8f):
  * per component: pixel SED (optionally PSF-corrected by the caller through sed_scale
  * [B] or NULL), detection coadd, sdss symmetry, thresh=0.1 weighted monotone sweep,

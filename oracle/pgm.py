@@ -307,15 +307,30 @@ def neighbour_offsets(width):
     return np.array([width * y + x for y, x in NEIGHBOURS])
 
 
+_SWEEP_CACHE = {}
+
+
+def _sweep_operator(shape, center, dtype):
+    """Memo of (order, weights, offsets) per (shape, centre, dtype), the analogue of the
+    reference's Cache (update.py:131-147, cache.py): building them costs an argsort."""
+    key = (tuple(shape), (int(center[0]), int(center[1])), np.dtype(dtype).str)
+    hit = _SWEEP_CACHE.get(key)
+    if hit is None:
+        if len(_SWEEP_CACHE) > 4096:
+            _SWEEP_CACHE.clear()
+        order = radius_order(shape, center)[1:].astype(np.int32)
+        w = np.ascontiguousarray(radial_weights(shape, center), dtype=dtype)
+        hit = (order, w, neighbour_offsets(shape[1]).astype(np.int32))
+        _SWEEP_CACHE[key] = hit
+    return hit
+
+
 def prox_weighted_monotonic(X, center, thresh=0.0):
     """update.monotonic default path -> operator.prox_strict_monotonic(use_nearest=False)
     -> operators_pybind11.prox_weighted_monotonic (update.py:106-156, operator.py:81-122,
     32-37).  X (H, W) float32/float64, mutated in place (must be C-contiguous)."""
-    shape = X.shape
-    order = radius_order(shape, center)
-    w = radial_weights(shape, center)
-    native.prox_weighted_monotonic(X.reshape(-1), w, neighbour_offsets(shape[1]),
-                                   order[1:], thresh)
+    order, w, offs = _sweep_operator(X.shape, center, X.dtype)
+    native.prox_weighted_monotonic(X.reshape(-1), w, offs, order, thresh)
     return X
 
 

@@ -74,6 +74,8 @@ _SIGNATURES = {
     "scarlet_backward_step": (c_int, [POINTER(ScarletBatch), c_int, _P]),
     "scarlet_source_update": (c_int, [POINTER(ScarletBatch), c_int, _P]),
     "scarlet_check_convergence": (c_int, [POINTER(ScarletBatch), c_double, _P]),
+    "scarlet_profile_begin": (c_int, [c_int]),
+    "scarlet_profile_end": (c_int, [_P, _P]),
     "scarlet_init_extended": (c_int, [POINTER(ScarletBatch), _P, c_float, _P, _P]),
 }
 

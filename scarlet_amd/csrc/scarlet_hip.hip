@@ -415,6 +415,44 @@ extern "C" int scarlet_host_apply_filter_f32(const float *image, int H, int W, c
 // =====================================================================================
 // 3. batched Blend.fit() engine
 // =====================================================================================
+// ---- optional per-kernel event timing (scarlet_profile_begin/end)
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> ev;     // 5 events per iteration
+    int iters = 0, cap = 0;
+};
+static Profiler g_prof;
+static inline void prof_mark(int slot, hipStream_t st)
+{
+    if (g_prof.on && g_prof.iters < g_prof.cap) (void)hipEventRecord(g_prof.ev[g_prof.iters * 5 + slot], st);
+}
+extern "C" int scarlet_profile_begin(int max_iterations)
+{
+    if (max_iterations <= 0) return set_err(SCARLET_E_ARG, "max_iterations <= 0");
+    for (auto e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.assign((size_t)max_iterations * 5, nullptr);
+    for (auto &e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
+    g_prof.cap = max_iterations; g_prof.iters = 0; g_prof.on = true;
+    return SCARLET_OK;
+}
+extern "C" int scarlet_profile_end(double total_ms[4], int64_t launches[4])
+{
+    if (!g_prof.on) return set_err(SCARLET_E_ARG, "profiler not active");
+    g_prof.on = false;
+    for (int k = 0; k < 4; ++k) { total_ms[k] = 0; launches[k] = 0; }
+    for (int i = 0; i < g_prof.iters; ++i) {
+        HIP_TRY(hipEventSynchronize(g_prof.ev[i * 5 + 4]));
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i * 5 + k], g_prof.ev[i * 5 + k + 1]));
+            total_ms[k] += ms; launches[k] += 1;
+        }
+    }
+    for (auto e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear(); g_prof.cap = g_prof.iters = 0;
+    return SCARLET_OK;
+}
+
 static int check_batch(const scarlet_batch *b)
 {
     if (!b) return set_err(SCARLET_E_ARG, "null batch");
@@ -464,13 +502,17 @@ extern "C" int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *
     GradArgs a = grad_args(b, approximate_L);
     dim3 grid(a.T, a.S);
     hipStream_t st = (hipStream_t)stream;
+    prof_mark(0, st);
     if (b->K <= 4) {
         hipLaunchKernelGGL((k_grad<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_mark(1, st);
         hipLaunchKernelGGL((k_step<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
     } else {
         hipLaunchKernelGGL((k_grad<SC_KMAX, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_mark(1, st);
         hipLaunchKernelGGL((k_step<SC_KMAX, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
     }
+    prof_mark(2, st);
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;
 }
@@ -537,7 +579,10 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
     for (int i = 0; i < max_iter; ++i) {
         if ((rc = scarlet_backward_step(b, approximate_L, stream))) return rc;
         if ((rc = launch_update(b, 1, 0, stream))) return rc;
+        prof_mark(3, st);
         if ((rc = scarlet_check_convergence(b, e_rel, stream))) return rc;
+        prof_mark(4, st);
+        if (g_prof.on && g_prof.iters < g_prof.cap) ++g_prof.iters;
         ++launched;
         if (check_every > 0 && (i + 1) % check_every == 0 && i + 1 < max_iter) {
             int h_count = 0;
