@@ -28,7 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_NAMES = ("k_grad", "k_step", "k_source_update", "k_converge")
+KERNEL_NAMES = ("k_grad", "k_step", "k_source_update", "k_converge", "k_iterate", "-", "-", "-")
 
 
 def algorithmic_bytes_per_scene_iteration(B, K, H, W):
@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-scenes", type=int, default=8, help="oracle scenes per host process")
     ap.add_argument("--cpu-iters", type=int, default=25)
+    ap.add_argument("--no-symmetric", action="store_true", help="ablation: drop the symmetry constraint")
+    ap.add_argument("--no-monotonic", action="store_true", help="ablation: drop the monotonicity constraint")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/)")
     args = ap.parse_args()
@@ -131,7 +133,8 @@ def main():
     torch.cuda.set_device(local if world > 1 else 0)
     distributed.init_from_env("nccl" if world > 1 else None)
 
-    batch = BlendBatch(images, centers, mse_capacity=args.steps + args.warmup + 1)
+    batch = BlendBatch(images, centers, mse_capacity=args.steps + args.warmup + 1,
+                       symmetric=not args.no_symmetric, monotonic=not args.no_monotonic)
     batch.init_extended(np.ones(B, dtype=np.float32) * 0.1)
     torch.cuda.synchronize()
     if args.warmup > 0:
@@ -146,8 +149,8 @@ def main():
     distributed.barrier()
     elapsed = time.perf_counter() - t0
     import ctypes
-    ms = (ctypes.c_double * 4)()
-    cnt = (ctypes.c_int64 * 4)()
+    ms = (ctypes.c_double * 8)()
+    cnt = (ctypes.c_int64 * 8)()
     _lib.check(_lib.lib.scarlet_profile_end(ms, cnt))
     assert launched == args.steps
     elapsed = distributed.max_over_ranks(elapsed)
@@ -162,7 +165,7 @@ def main():
     total_scene_iters = float(S) * world * args.steps
     value = total_scene_iters / elapsed
     bytes_unit = algorithmic_bytes_per_scene_iteration(B, K, H, W)
-    dom = int(np.argmax([ms[i] for i in range(4)]))
+    dom = int(np.argmax([ms[i] for i in range(8)]))
     avg_ms = ms[dom] / max(1, cnt[dom])
     achieved = bytes_unit * S / (avg_ms * 1e-3) / 1e9
     it_ms = 1e3 * elapsed / args.steps
@@ -192,7 +195,7 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": args.traffic_bytes,
                      "algorithmic_bytes_per_launch": bytes_unit * S, "avg_launch_ms": avg_ms,
-                     "per_kernel_avg_ms": {KERNEL_NAMES[i]: ms[i] / max(1, cnt[i]) for i in range(4)},
+                     "per_kernel_avg_ms": {KERNEL_NAMES[i]: ms[i] / cnt[i] for i in range(8) if cnt[i]},
                      "whole_iteration_frac": bytes_unit * S / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
     if cpu is not None:

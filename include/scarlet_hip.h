@@ -212,10 +212,10 @@ int scarlet_check_convergence(scarlet_batch *b, double e_rel, void *stream);
 /* Per-kernel timing of scarlet_fit with hipEvents recorded on the launch stream (used by
  * bench.py for the roofline line).  begin: allocate events for up to max_iterations
  * iterations and start recording; end: synchronise, return per kernel class
- * {0 grad, 1 step, 2 source_update, 3 converge} the summed milliseconds and launch
- * counts, and stop recording. */
+ * {0 k_grad, 1 k_step, 2 k_source_update, 3 k_converge, 4 k_iterate (fused), 5-7 unused}
+ * the summed milliseconds and launch counts, and stop recording. */
 int scarlet_profile_begin(int max_iterations);
-int scarlet_profile_end(double total_ms[4], int64_t launches[4]);
+int scarlet_profile_end(double total_ms[8], int64_t launches[8]);
 
 /* ExtendedSource initialisation on device (source.py:139-180, rank f1 of SURVEY 8f):
  * per component: pixel SED (optionally PSF-corrected by the caller through sed_scale

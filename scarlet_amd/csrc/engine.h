@@ -175,6 +175,63 @@ __device__ inline double jacobi_lambda_max(double *A, int n, int ld)
     return l;
 }
 
+// Register-resident variant for the fused kernel: the whole (padded) N x N matrix lives in
+// VGPRs of ONE lane, loops fully unrolled (no LDS round trips on the rotation chain).
+// Rotation angles are computed in float32 (one v_rcp/v_sqrt each), then (c, s) is
+// re-orthonormalised in float64 with one Newton step, so the similarity transforms stay
+// orthogonal to ~1e-14 while the scalar part costs a handful of instructions; an angle
+// that is only float32-accurate merely leaves a 1e-7-relative off-diagonal residue that the
+// next sweep removes.  Eigenvalues are accurate to float64 round-off.
+template <int N>
+__device__ inline double jacobi_lambda_max_reg(const double *Ain, int n, int ld)
+{
+    double A[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) A[i][j] = (i < n && j < n) ? Ain[i * ld + j] : 0.0;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0, diag = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            diag += A[i][i] * A[i][i];
+#pragma unroll
+            for (int j = i + 1; j < N; ++j) off += A[i][j] * A[i][j];
+        }
+        if (off <= 1e-30 * diag) break;
+#pragma unroll
+        for (int p = 0; p < N - 1; ++p)
+#pragma unroll
+            for (int q = p + 1; q < N; ++q) {
+                const double apq = A[p][q];
+                if (apq != 0.0) {
+                    const float th = (float)((A[q][q] - A[p][p]) / (2.0 * apq));
+                    const float tf = (th >= 0.f ? 1.f : -1.f) / (fabsf(th) + sqrtf(th * th + 1.f));
+                    const float cf = 1.0f / sqrtf(tf * tf + 1.f);
+                    double c = (double)cf, sn = (double)(tf * cf);
+                    const double fix = 1.5 - 0.5 * (c * c + sn * sn);      // Newton step of rsqrt
+                    c *= fix; sn *= fix;
+#pragma unroll
+                    for (int r = 0; r < N; ++r) {
+                        const double arp = A[r][p], arq = A[r][q];
+                        A[r][p] = c * arp - sn * arq;
+                        A[r][q] = sn * arp + c * arq;
+                    }
+#pragma unroll
+                    for (int r = 0; r < N; ++r) {
+                        const double apr = A[p][r], aqr = A[q][r];
+                        A[p][r] = c * apr - sn * aqr;
+                        A[q][r] = sn * apr + c * aqr;
+                    }
+                }
+            }
+    }
+    double l = A[0][0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) l = fmax(l, A[i][i]);
+    return l;
+}
+
 // ------------------------------------------------------------------------------------
 // k_step: finish _backward (mse), _set_lipschitz, and the gradient step of Blend.fit.
 template <int KM, int BM>
@@ -427,4 +484,95 @@ __global__ void k_converge(int S, int K, const double *conv, int *flags, int *ac
         }
         if (done) active[s] = 0;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// k_source_update_w: the same pipeline with one WAVE per component (wave_ops.h), four
+// components per 256-thread workgroup, no workgroup barriers.  H, W <= 64.
+#include "wave_ops.h"
+
+__device__ inline void wave_pipeline(const UpdateArgs &a, int c, float *lds_wave)
+{
+    const int s = c / a.K;
+    const int H = a.H, W = a.W, HW = H * W, B = a.B;
+    const int lane = lane_id();
+    Tile t; t.H = H; t.W = W; t.LW = tile_stride(W); t.m = lds_wave;
+    float *vec = lds_wave + H * t.LW;
+    const int c0 = a.cur[s];
+    const int wbuf = a.in_iteration ? 1 - c0 : c0;
+    float *gm = a.morph[wbuf] + (size_t)c * HW;
+    for (int i = lane; i < HW; i += SC_WAVE) t.m[(i / W) * t.LW + (i % W)] = gm[i];
+    wave_sync();
+    const int it = a.force_it0 ? 0 : a.it[s] + (a.in_iteration ? 1 : 0);
+    int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
+    int stat = 0;
+    wave_max_pixel(t, cy, cx, stat);
+    if (a.symmetric) {
+        double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
+        if (it % 5 == 0) {
+            wave_centroid(t, a.centroid_psf, a.centroid_P, cy, cx, dy, dx, stat);
+            if (lane == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
+        }
+        const bool none = (dy != dy);
+        wave_symmetry(t, cy, cx, none ? SCARLET_SYM_SOFT : SCARLET_SYM_KSPACE, 1.0f, dy, dx, false, 0.f, vec);
+    }
+    if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f);
+    if (lane == 0) { a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
+    const float step_morph = 1.0f / (float)a.lipschitz[2 * s + 1];
+    float vmax = -INFINITY;
+    bool anynan = false;
+    for (int i = lane; i < HW; i += SC_WAVE) {
+        float *p = &t.m[(i / W) * t.LW + (i % W)];
+        float v = *p;
+        if (a.l0_thresh >= 0.f && fabsf(v) < a.l0_thresh * step_morph) v = 0.f;
+        if (a.l1_thresh >= 0.f) {
+            const float mag = fabsf(v) - a.l1_thresh * step_morph;
+            v = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
+        }
+        if (v < 0.f) v = 0.f;
+        *p = v;
+        anynan |= (v != v);
+        vmax = fmaxf(vmax, v);
+    }
+    float norm = wave_max(vmax);
+    if (__any(anynan)) norm = __builtin_nanf("");
+    if (!(norm > 0.f) || isinf(norm)) stat |= SCARLET_STATUS_NONFINITE;
+    const float *gl = a.in_iteration ? a.morph[c0] + (size_t)c * HW : nullptr;
+    double d2 = 0, n2 = 0;
+    for (int i = lane; i < HW; i += SC_WAVE) {
+        const float v = t.m[(i / W) * t.LW + (i % W)] / norm;
+        gm[i] = v;
+        if (gl) { const float d = gl[i] - v; d2 += (double)(d * d); }
+        n2 += (double)(v * v);
+    }
+    d2 = wave_sum(d2); n2 = wave_sum(n2);
+    // SED: positive, * norm (update.py:27-32,62-65) and its convergence sums
+    float *gs = a.sed[wbuf] + (size_t)c * B;
+    const float *gsl = a.in_iteration ? a.sed[c0] + (size_t)c * B : nullptr;
+    double d2s = 0, n2s = 0;
+    if (lane < B) {
+        float v = gs[lane];
+        if (v < 0.f) v = 0.f;
+        v = v * norm;
+        gs[lane] = v;
+        if (gsl) { const float d = gsl[lane] - v; d2s = (double)(d * d); }
+        n2s = (double)(v * v);
+    }
+    d2s = wave_sum(d2s); n2s = wave_sum(n2s);
+    if (lane == 0) {
+        a.conv[4 * c + 0] = d2s; a.conv[4 * c + 1] = n2s;
+        a.conv[4 * c + 2] = d2;  a.conv[4 * c + 3] = n2;
+        if (stat) atomicOr(&a.status[s], stat);
+    }
+}
+
+__global__ __launch_bounds__(SC_BLOCK) void k_source_update_w(UpdateArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int wid = threadIdx.x / SC_WAVE;
+    const int c = blockIdx.x * SC_NWAVES + wid;
+    if (c >= a.S * a.K) return;
+    if (!a.force_it0 && !a.active[c / a.K]) return;
+    const int per_wave = a.H * tile_stride(a.W) + SC_WAVE_VEC_FLOATS;
+    wave_pipeline(a, c, lds + (size_t)wid * per_wave);
 }

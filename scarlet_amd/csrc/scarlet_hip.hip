@@ -5,11 +5,13 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "common.h"
 #include "prox_ops.h"
 #include "engine.h"
+#include "fused.h"
 
 __constant__ unsigned short sc_nfl_table[SC_NFL_MAX];
 
@@ -137,6 +139,52 @@ __global__ __launch_bounds__(SC_BLOCK) void k_operator(OpArgs a)
     if (threadIdx.x == 0 && stat && a.status) atomicOr(&a.status[c], stat);
 }
 
+// the same operators, one wave per array (wave_ops.h), H, W <= 64
+__global__ __launch_bounds__(SC_BLOCK) void k_operator_w(OpArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int wid = threadIdx.x / SC_WAVE, lane = threadIdx.x & (SC_WAVE - 1);
+    const int c = blockIdx.x * SC_NWAVES + wid;
+    if (c >= a.n) return;
+    const int H = a.H, W = a.W, HW = H * W;
+    Tile t; t.H = H; t.W = W; t.LW = tile_stride(W);
+    t.m = lds + (size_t)wid * (H * t.LW + SC_WAVE_VEC_FLOATS);
+    float *vec = t.m + H * t.LW;
+    float *g = a.x + (size_t)c * HW;
+    for (int i = lane; i < HW; i += SC_WAVE) t.m[(i / W) * t.LW + (i % W)] = g[i];
+    wave_sync();
+    int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
+    int stat = 0;
+    bool writeback = true;
+    switch (a.op) {
+    case OP_MONO_WEIGHTED: wave_monotonic<float>(t, cy, cx, a.thresh); break;
+    case OP_SYMMETRY: {
+        const double dy = a.shifts ? a.shifts[2 * c] : 0.0, dx = a.shifts ? a.shifts[2 * c + 1] : 0.0;
+        wave_symmetry(t, cy, cx, a.algorithm, a.strength, dy, dx, a.use_fill != 0, a.fill, vec);
+        break;
+    }
+    case OP_MAX_PIXEL:
+        wave_max_pixel(t, cy, cx, stat);
+        if (lane == 0) { a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
+        writeback = false;
+        break;
+    case OP_CENTROID: {
+        double dy = 0, dx = 0;
+        wave_centroid(t, a.psf, a.P, cy, cx, dy, dx, stat);
+        if (lane == 0) {
+            a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx;
+            a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx;
+        }
+        writeback = false;
+        break;
+    }
+    }
+    wave_sync();
+    if (writeback)
+        for (int i = lane; i < HW; i += SC_WAVE) g[i] = t.m[(i / W) * t.LW + (i % W)];
+    if (lane == 0 && stat && a.status) atomicOr(&a.status[c], stat);
+}
+
 static int launch_operator(OpArgs a, void *stream)
 {
     if (!a.x || a.n < 0 || a.H <= 0 || a.W <= 0 || a.W > 256 || !a.centers)
@@ -144,10 +192,18 @@ static int launch_operator(OpArgs a, void *stream)
     if (a.n == 0) return SCARLET_OK;
     int rc = ensure_tables();
     if (rc) return rc;
-    const size_t lds = update_lds_bytes(a.H, a.W);
-    rc = allow_lds(k_operator, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_operator, dim3(a.n), dim3(SC_BLOCK), lds, (hipStream_t)stream, a);
+    if (a.H <= 64 && a.W <= 64 && a.op != OP_MONO_NEAREST && !getenv("SCARLET_FORCE_BLOCK_UPDATE")) {
+        const size_t lds = sizeof(float) * SC_NWAVES * ((size_t)a.H * tile_stride(a.W) + SC_WAVE_VEC_FLOATS);
+        rc = allow_lds(k_operator_w, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_operator_w, dim3((a.n + SC_NWAVES - 1) / SC_NWAVES), dim3(SC_BLOCK), lds,
+                           (hipStream_t)stream, a);
+    } else {
+        const size_t lds = update_lds_bytes(a.H, a.W);
+        rc = allow_lds(k_operator, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_operator, dim3(a.n), dim3(SC_BLOCK), lds, (hipStream_t)stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;
 }
@@ -416,40 +472,52 @@ extern "C" int scarlet_host_apply_filter_f32(const float *image, int H, int W, c
 // 3. batched Blend.fit() engine
 // =====================================================================================
 // ---- optional per-kernel event timing (scarlet_profile_begin/end)
+#define SC_NCLASS 8
 struct Profiler {
     bool on = false;
-    std::vector<hipEvent_t> ev;     // 5 events per iteration
-    int iters = 0, cap = 0;
+    std::vector<hipEvent_t> ev;     // pairs (start, stop)
+    std::vector<int> cls;
+    int used = 0, cap = 0;
 };
 static Profiler g_prof;
-static inline void prof_mark(int slot, hipStream_t st)
+static inline void prof_start(int cls, hipStream_t st)
 {
-    if (g_prof.on && g_prof.iters < g_prof.cap) (void)hipEventRecord(g_prof.ev[g_prof.iters * 5 + slot], st);
+    if (g_prof.on && g_prof.used < g_prof.cap) {
+        g_prof.cls[g_prof.used] = cls;
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
+    }
+}
+static inline void prof_stop(hipStream_t st)
+{
+    if (g_prof.on && g_prof.used < g_prof.cap) {
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
+        ++g_prof.used;
+    }
 }
 extern "C" int scarlet_profile_begin(int max_iterations)
 {
     if (max_iterations <= 0) return set_err(SCARLET_E_ARG, "max_iterations <= 0");
     for (auto e : g_prof.ev) (void)hipEventDestroy(e);
-    g_prof.ev.assign((size_t)max_iterations * 5, nullptr);
+    const int cap = max_iterations * 4;
+    g_prof.ev.assign((size_t)cap * 2, nullptr);
+    g_prof.cls.assign(cap, 0);
     for (auto &e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
-    g_prof.cap = max_iterations; g_prof.iters = 0; g_prof.on = true;
+    g_prof.cap = cap; g_prof.used = 0; g_prof.on = true;
     return SCARLET_OK;
 }
-extern "C" int scarlet_profile_end(double total_ms[4], int64_t launches[4])
+extern "C" int scarlet_profile_end(double total_ms[SC_NCLASS], int64_t launches[SC_NCLASS])
 {
     if (!g_prof.on) return set_err(SCARLET_E_ARG, "profiler not active");
     g_prof.on = false;
-    for (int k = 0; k < 4; ++k) { total_ms[k] = 0; launches[k] = 0; }
-    for (int i = 0; i < g_prof.iters; ++i) {
-        HIP_TRY(hipEventSynchronize(g_prof.ev[i * 5 + 4]));
-        for (int k = 0; k < 4; ++k) {
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i * 5 + k], g_prof.ev[i * 5 + k + 1]));
-            total_ms[k] += ms; launches[k] += 1;
-        }
+    for (int k = 0; k < SC_NCLASS; ++k) { total_ms[k] = 0; launches[k] = 0; }
+    for (int i = 0; i < g_prof.used; ++i) {
+        HIP_TRY(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+        total_ms[g_prof.cls[i]] += ms; launches[g_prof.cls[i]] += 1;
     }
     for (auto e : g_prof.ev) (void)hipEventDestroy(e);
-    g_prof.ev.clear(); g_prof.cap = g_prof.iters = 0;
+    g_prof.ev.clear(); g_prof.cls.clear(); g_prof.cap = g_prof.used = 0;
     return SCARLET_OK;
 }
 
@@ -502,17 +570,19 @@ extern "C" int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *
     GradArgs a = grad_args(b, approximate_L);
     dim3 grid(a.T, a.S);
     hipStream_t st = (hipStream_t)stream;
-    prof_mark(0, st);
     if (b->K <= 4) {
+        prof_start(0, st);
         hipLaunchKernelGGL((k_grad<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
-        prof_mark(1, st);
+        prof_stop(st); prof_start(1, st);
         hipLaunchKernelGGL((k_step<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_stop(st);
     } else {
+        prof_start(0, st);
         hipLaunchKernelGGL((k_grad<SC_KMAX, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
-        prof_mark(1, st);
+        prof_stop(st); prof_start(1, st);
         hipLaunchKernelGGL((k_step<SC_KMAX, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_stop(st);
     }
-    prof_mark(2, st);
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;
 }
@@ -529,10 +599,20 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
     u.status = b->status; u.symmetric = b->symmetric; u.monotonic = b->monotonic;
     u.l0_thresh = b->l0_thresh; u.l1_thresh = b->l1_thresh;
     u.centroid_psf = b->centroid_psf; u.centroid_P = b->centroid_P; u.conv = ws_conv(b); u.force_it0 = force_it0;
-    const size_t lds = update_lds_bytes(b->H, b->W);
-    rc = allow_lds(k_source_update, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_source_update, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
+    if (b->H <= 64 && b->W <= 64 && !getenv("SCARLET_FORCE_BLOCK_UPDATE")) {
+        // one wave per component, four components per workgroup (wave_ops.h)
+        const size_t lds = sizeof(float) * SC_NWAVES * ((size_t)b->H * tile_stride(b->W) + SC_WAVE_VEC_FLOATS);
+        rc = allow_lds(k_source_update_w, lds);
+        if (rc) return rc;
+        const int n = b->S * b->K;
+        hipLaunchKernelGGL(k_source_update_w, dim3((n + SC_NWAVES - 1) / SC_NWAVES), dim3(SC_BLOCK), lds,
+                           (hipStream_t)stream, u);
+    } else {
+        const size_t lds = update_lds_bytes(b->H, b->W);
+        rc = allow_lds(k_source_update, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_source_update, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
+    }
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;
 }
@@ -550,6 +630,50 @@ extern "C" int scarlet_check_convergence(scarlet_batch *b, double e_rel, void *s
     if (rc) return rc;
     hipLaunchKernelGGL(k_converge, dim3((b->S + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0, (hipStream_t)stream,
                        b->S, b->K, ws_conv(b), b->flags, b->active, b->it, b->cur, e_rel * e_rel);
+    HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
+}
+
+// ---- fused one-kernel iteration (fused.h)
+static size_t fused_lds_bytes(const scarlet_batch *b)
+{
+    return sizeof(float) * ((size_t)b->K * b->H * tile_stride(b->W) + SC_NWAVES * SC_WAVE_VEC_FLOATS);
+}
+static bool fused_ok(const scarlet_batch *b, int approximate_L)
+{
+    if (approximate_L || getenv("SCARLET_NO_FUSED")) return false;
+    if (b->H > 64 || b->W > 64 || (b->W & 3) || b->H < 3 || b->W < 3) return false;
+    return fused_lds_bytes(b) <= LDS_LIMIT - 4096;
+}
+static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
+{
+    int rc = ensure_tables();
+    if (rc) return rc;
+    FusedArgs f;
+    f.S = b->S; f.K = b->K; f.B = b->B; f.H = b->H; f.W = b->W;
+    f.images = b->images; f.weights = b->weights; f.weight_scalar = b->weight_scalar;
+    f.sed[0] = b->sed[0]; f.sed[1] = b->sed[1]; f.morph[0] = b->morph[0]; f.morph[1] = b->morph[1];
+    f.cur = b->cur; f.fix_sed = b->fix_sed; f.fix_morph = b->fix_morph;
+    f.centers = b->centers; f.shifts = b->shifts; f.flags = b->flags;
+    f.lipschitz = b->lipschitz; f.mse = b->mse; f.mse_capacity = b->mse_capacity;
+    f.it = b->it; f.active = b->active; f.status = b->status;
+    f.symmetric = b->symmetric; f.monotonic = b->monotonic; f.l0_thresh = b->l0_thresh; f.l1_thresh = b->l1_thresh;
+    f.centroid_psf = b->centroid_psf; f.centroid_P = b->centroid_P; f.e_rel2 = e_rel * e_rel;
+    // diagnostics: SCARLET_STAMPS=1 writes phase stamps into the (otherwise unused) partials area
+    f.stamps = (getenv("SCARLET_STAMPS") && n_partials(b->K, b->B) >= 16) ? (long long *)ws_partials(b) : nullptr;
+    const size_t lds = fused_lds_bytes(b);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_ITERATE(KM_, BM_)                                                                       \
+    do {                                                                                               \
+        rc = allow_lds(k_iterate<KM_, BM_>, lds);                                                      \
+        if (rc) return rc;                                                                             \
+        prof_start(4, st);                                                                             \
+        hipLaunchKernelGGL((k_iterate<KM_, BM_>), dim3(b->S), dim3(SC_BLOCK), lds, st, f);             \
+        prof_stop(st);                                                                                 \
+    } while (0)
+    if (b->K <= 4) { if (b->B <= 6) LAUNCH_ITERATE(4, 6); else LAUNCH_ITERATE(4, SC_BMAX); }
+    else           { if (b->B <= 6) LAUNCH_ITERATE(SC_KMAX, 6); else LAUNCH_ITERATE(SC_KMAX, SC_BMAX); }
+#undef LAUNCH_ITERATE
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;
 }
@@ -576,13 +700,18 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
     hipStream_t st = (hipStream_t)stream;
     int launched = 0;
     int *d_count = (int *)((char *)b->workspace + scarlet_batch_workspace_bytes(b) - 64);
+    const bool fused = fused_ok(b, approximate_L);
     for (int i = 0; i < max_iter; ++i) {
-        if ((rc = scarlet_backward_step(b, approximate_L, stream))) return rc;
-        if ((rc = launch_update(b, 1, 0, stream))) return rc;
-        prof_mark(3, st);
-        if ((rc = scarlet_check_convergence(b, e_rel, stream))) return rc;
-        prof_mark(4, st);
-        if (g_prof.on && g_prof.iters < g_prof.cap) ++g_prof.iters;
+        if (fused) {
+            if ((rc = launch_fused(b, e_rel, stream))) return rc;
+        } else {
+            if ((rc = scarlet_backward_step(b, approximate_L, stream))) return rc;
+            prof_start(2, st);
+            if ((rc = launch_update(b, 1, 0, stream))) return rc;
+            prof_stop(st); prof_start(3, st);
+            if ((rc = scarlet_check_convergence(b, e_rel, stream))) return rc;
+            prof_stop(st);
+        }
         ++launched;
         if (check_every > 0 && (i + 1) % check_every == 0 && i + 1 < max_iter) {
             int h_count = 0;

@@ -1,0 +1,349 @@
+// wave_ops.h -- the constraint pipeline with ONE 64-lane wavefront per component.
+//
+// Why wave-level: the radial sweep is a chain of ~100-190 dependent levels.  With a
+// 256-thread workgroup per component (prox_ops.h) three of the four waves idle through the
+// small levels and every level pays an s_barrier; with one wave per component there are
+// no barriers at all (LDS operations of one wave complete in order), four components
+// progress concurrently on the four SIMDs of a CU, and other workgroups hide the chain
+// latency.  Requires H, W <= 64 (the k-space GEMM keeps T = X.B in 64 accumulator VGPRs);
+// larger images use the workgroup-level code in prox_ops.h.
+//
+// Same reference rows as prox_ops.h (a8-a17); see the comments there for the maths.
+#pragma once
+#include "common.h"
+#include "prox_ops.h"
+
+// order LDS traffic of this wave (compiler + lgkmcnt), no s_barrier
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (SC_WAVE - 1); }
+
+// ---------------------------------------------------------------- a8 max_pixel
+// np.argmax order: larger value wins, NaN beats everything, ties -> smaller index.
+__device__ __forceinline__ bool argmax_better(float va, int ia, float vb, int ib)
+{
+    const bool na = va != va, nb = vb != vb;
+    if (na || nb) return (na && nb) ? ia < ib : na;
+    return va > vb || (va == vb && ia < ib);
+}
+__device__ inline void wave_max_pixel(const Tile &t, int &cy, int &cx, int &status_bits)
+{
+    if (cy - 2 < 0 || cx - 2 < 0) { status_bits |= SCARLET_STATUS_CENTER_AT_EDGE; return; }
+    const int lane = lane_id();
+    const int wy = lane / 5, wx = lane - wy * 5;
+    const int y = cy - 2 + wy, x = cx - 2 + wx;
+    const bool in = lane < 25 && y < t.H && x < t.W;
+    float v = in ? t.m[y * t.LW + x] : -INFINITY;
+    int idx = in ? lane : 1 << 20;                     // row-major rank inside the window
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(v, o, SC_WAVE);
+        const int i2 = __shfl_xor(idx, o, SC_WAVE);
+        if (argmax_better(v2, i2, v, idx)) { v = v2; idx = i2; }
+    }
+    cy = cy - 2 + idx / 5;
+    cx = cx - 2 + idx % 5;
+}
+
+// ---------------------------------------------------------------- a9 centroid
+__device__ inline void wave_centroid(const Tile &t, const double *__restrict__ psf, int P,
+                                     int &cy, int &cx, double &dy, double &dx, int &status_bits)
+{
+    const int rad = P / 2;
+    const int ry = min(min(cy, t.H - 1 - cy), rad), rx = min(min(cx, t.W - 1 - cx), rad);
+    const int hh = 2 * ry + 1, ww = 2 * rx + 1;
+    double s0 = 0, sy = 0, sx = 0;
+    for (int i = lane_id(); i < hh * ww; i += SC_WAVE) {
+        const int iy = i / ww, ix = i - iy * ww;
+        const double w = (double)t.m[(cy - ry + iy) * t.LW + (cx - rx + ix)] *
+                         psf[(rad - ry + iy) * P + (rad - rx + ix)];
+        s0 += w; sy += iy * w; sx += ix * w;
+    }
+    s0 = wave_sum(s0); sy = wave_sum(sy); sx = wave_sum(sx);
+    const double my = sy / s0, mx = sx / s0;
+    if (!(my == my) || !(mx == mx) || isinf(my) || isinf(mx)) {
+        status_bits |= SCARLET_STATUS_NONFINITE; dy = 0; dx = 0;
+        return;
+    }
+    const double wy = rint(my), wx = rint(mx);
+    const int ncy = (int)wy + (cy - ry), ncx = (int)wx + (cx - rx);
+    dy = wy - my; dx = wx - mx; cy = ncy; cx = ncx;
+}
+
+// ---------------------------------------------------------------- a10/a11 sweep
+// Wedge/row-walk form of the weighted sweep.  A pixel at offset (X, Y) from the peak has
+// a = max(|X|,|Y|) >= 1, b = min(|X|,|Y|), level = 2a + b; its strictly closer neighbours
+// are, in (major, minor) coordinates,
+//     n1 = (a-1, b-1)  cos ~ (a+b)/sqrt2   valid iff a+b > 1 (and in bounds when b = 0)
+//     n2 = (a-1, b  )  cos ~ a             always
+//     n3 = (a-1, b+1)  cos ~ (a-b)/sqrt2   valid iff b < a-1 and in bounds
+//     n4 = (a,   b-1)  cos ~ b             valid iff b > 0
+// (the 1/r factor of the cosines cancels in the normalisation).  The image is cut into
+// four wedges: right/left (|X| >= |Y|, "x-major", one walker per ROW) and down/up
+// (|X| < |Y|, "y-major", one walker per COLUMN).  A walker moves outwards one pixel every
+// two levels, so at level ell only minor indices of one parity are active: lane k of a
+// 32-lane half handles minor index 2k + ((ell + c_minor) & 1).  One wave64 covers the
+// right+left wedges in one trip and the down+up wedges in a second; the four neighbour
+// addresses are constant offsets from the walker's own address.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // <= 1 ulp
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+
+// Per-lane walker: everything that does not change along a walk (one per wedge trip and
+// level parity), so that a level costs ~40 VALU instructions per trip.
+template <typename T>
+struct Walker {
+    int base, step, b, amin, lim;      // p = base + a*step ; a = (ell - b) >> 1 in [amin, lim]
+    int sa, off1, off3, off4;          // neighbour offsets from p (0 when never valid)
+    bool valid, ok1, ok3;
+    T c4;
+};
+
+template <typename T>
+__device__ __forceinline__ Walker<T> make_walker(bool xmajor, int e, int H, int W, int LW, int cy, int cx,
+                                                 int half, int k2)
+{
+    Walker<T> w;
+    const int cmin = xmajor ? cy : cx, cmaj = xmajor ? cx : cy;
+    const int dimmin = xmajor ? H : W, dimmaj = xmajor ? W : H;
+    const int strmin = xmajor ? LW : 1, strmaj = xmajor ? 1 : LW;
+    const int dir = half ? -1 : 1;
+    const int mi = k2 + ((e + cmin) & 1);                       // minor index active at levels = e (mod 2)
+    const int Yb = mi - cmin;
+    const int s = Yb > 0 ? -1 : 1;                              // minor step towards the axis
+    w.b = Yb < 0 ? -Yb : Yb;
+    w.valid = mi < dimmin;
+    w.ok1 = (unsigned)(mi + s) < (unsigned)dimmin;
+    w.ok3 = (unsigned)(mi - s) < (unsigned)dimmin;
+    w.amin = xmajor ? max(w.b, 1) : w.b + 1;
+    w.lim = half ? cmaj : dimmaj - 1 - cmaj;
+    w.base = mi * strmin + cmaj * strmaj;
+    w.step = dir * strmaj;
+    w.sa = -w.step;
+    w.off1 = w.ok1 ? w.sa + s * strmin : 0;
+    w.off3 = w.ok3 ? w.sa - s * strmin : 0;
+    w.off4 = w.b > 0 ? s * strmin : 0;
+    w.c4 = (T)w.b;
+    return w;
+}
+
+template <typename T>
+__device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thresh)
+{
+    const int H = t.H, W = t.W, LW = t.LW;
+    T *m = t.m;
+    const int lane = lane_id(), half = lane >> 5, k2 = (lane & 31) << 1;
+    const int mxr = max(cx, W - 1 - cx), myr = max(cy, H - 1 - cy);
+    const int Lall = 2 * max(mxr, myr) + min(mxr, myr);
+    const T one_minus = (T)1 - thresh;
+    const T R2 = (T)0.70710678118654752440;
+    const int psafe = min(1, H - 1) * LW + min(1, W - 1);       // interior address for idle lanes
+    // walkers: [trip: 0 = right/left wedges, 1 = down/up wedges][level parity]
+    const Walker<T> wx0 = make_walker<T>(true, 0, H, W, LW, cy, cx, half, k2);
+    const Walker<T> wx1 = make_walker<T>(true, 1, H, W, LW, cy, cx, half, k2);
+    const Walker<T> wy0 = make_walker<T>(false, 0, H, W, LW, cy, cx, half, k2);
+    const Walker<T> wy1 = make_walker<T>(false, 1, H, W, LW, cy, cx, half, k2);
+    struct Px { int p; bool act; T x0, x1, x2, x3, x4, c1, c2, c3, c4; };
+    auto gather = [&](int ell, const Walker<T> &w) {
+        Px q;
+        const int a = (ell - w.b) >> 1;
+        q.act = w.valid && a >= w.amin && a <= w.lim;
+        q.p = q.act ? w.base + a * w.step : psafe;
+        q.c1 = (w.ok1 && a + w.b > 1) ? (T)(a + w.b) * R2 : (T)0;
+        q.c2 = (T)a;
+        q.c3 = (w.ok3 && w.b < a - 1) ? (T)(a - w.b) * R2 : (T)0;
+        q.c4 = w.c4;
+        q.x0 = m[q.p]; q.x2 = m[q.p + w.sa]; q.x1 = m[q.p + w.off1];
+        q.x3 = m[q.p + w.off3]; q.x4 = m[q.p + w.off4];
+        return q;
+    };
+    auto finish = [&](const Px &q) {
+        const T inv = fast_rcp(q.c1 + q.c2 + q.c3 + q.c4);
+        // unused neighbours were read from a dummy address: mask them (0 * NaN != 0)
+        const T t1 = q.c1 > 0 ? q.x1 * q.c1 : (T)0, t3 = q.c3 > 0 ? q.x3 * q.c3 : (T)0;
+        const T t4 = q.c4 > 0 ? q.x4 * q.c4 : (T)0;
+        const T cap = ((q.x2 * q.c2 + t1) + (t3 + t4)) * inv * one_minus;
+        if (q.act && cap < q.x0) m[q.p] = cap;
+    };
+    for (int ell = 1; ell <= Lall; ell += 2) {
+        {   // odd level
+            const Px qa = gather(ell, wx1);
+            const Px qb = gather(ell, wy1);
+            finish(qa);
+            finish(qb);
+            wave_sync();
+        }
+        if (ell + 1 <= Lall) {   // even level
+            const Px qa = gather(ell + 1, wx0);
+            const Px qb = gather(ell + 1, wy0);
+            finish(qa);
+            finish(qb);
+            wave_sync();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- a16 flip symmetry
+template <typename T>
+__device__ inline void wave_flip_symmetry(const TileT<T> &t, const SymWindow &s, bool sdss, T strength)
+{
+    T *m = t.m;
+    const int n = s.h * s.w;
+    const T a = (T)(0.5 * (double)strength), bq = (T)1 - strength;
+    for (int i = lane_id(); 2 * i <= n - 1; i += SC_WAVE) {
+        const int jx = n - 1 - i;
+        const int iy = i / s.w, ix = i - iy * s.w;
+        const int jy = jx / s.w, jxx = jx - jy * s.w;
+        T *pi = &m[(s.y0 + iy) * t.LW + s.x0 + ix];
+        T *pj = &m[(s.y0 + jy) * t.LW + s.x0 + jxx];
+        const T xi = *pi, xj = *pj;
+        if (sdss) { const T r = xj < xi ? xj : xi; *pi = r; *pj = r; }
+        else { *pi = a * (xi + xj) + bq * xi; *pj = a * (xj + xi) + bq * xj; }
+    }
+    wave_sync();
+}
+
+// ---------------------------------------------------------------- a17 k-space symmetry
+// out = 1/2 X + 1/2 [A (X B) + s (sigma sigma^T X) C], X<=0 -> 0   (see prox_ops.h).
+// T = X B (up to 64 x 64) stays in 16 accumulator tiles (64 VGPRs); the second product
+// consumes it straight from the accumulators: accumulator register r of lane (q = lane>>4)
+// holds row 4q + r of a 16-row tile, so k-step r of the second MFMA sums over rows
+// {r, 4+r, 8+r, 12+r} and the Hankel operand is simply read at the matching index.
+// vec: LDS floats, 2*64 (av) + 2*64 (bv) + 2*64 (cv) + 64 (zv) per wave.
+__device__ inline void wave_kspace_symmetry(const Tile &t, const SymWindow &s, double dy, double dx,
+                                            float *vec)
+{
+    float *m = t.m;
+    const int LW = t.LW;
+    const int h = s.h, w = s.w, ry = h / 2, rx = w / 2;
+    const int hp = round16(h), wp = round16(w);
+    const int ntr = hp >> 4, ntc = wp >> 4;
+    float *av = vec, *bv = vec + 128, *cv = vec + 256, *zv = vec + 384;
+    const int Fy = dev_next_fast_len(2 * h + 10);
+    int Fx = dev_next_fast_len(2 * w + 10);
+    while (Fx & 1) Fx = dev_next_fast_len(Fx + 1);
+    const int lane = lane_id();
+    const double s2y = sinpi(2.0 * dy), s2x = sinpi(2.0 * dx), c2x = cospi(2.0 * dx);
+    for (int q = lane; q < 128; q += SC_WAVE) {
+        float va = 0.f, vb = 0.f, vc = 0.f;
+        if (q <= 2 * (h - 1)) {
+            const int n = q - 2 * ry;
+            const double tt = (double)n - 2.0 * dy;
+            const double sn = sinpi(tt / Fy), cs = cospi(tt / Fy);
+            const double spt = (n & 1) ? s2y : -s2y;
+            va = (float)(sn == 0.0 ? 1.0 : ((Fy & 1) ? spt / (Fy * sn) : spt * cs / (Fy * sn)));
+        }
+        if (q <= 2 * (w - 1)) {
+            const int n = q - 2 * rx;
+            const double tt = (double)n - 2.0 * dx;
+            const double sn = sinpi(tt / Fx), cs = cospi(tt / Fx);
+            const double spt = (n & 1) ? s2x : -s2x;
+            const double cpt = (n & 1) ? -c2x : c2x;
+            if (sn == 0.0) { vb = 1.f; vc = 0.f; }
+            else { vb = (float)(spt * cs / (Fx * sn)); vc = (float)(-(1.0 - cpt) * cs / (Fx * sn)); }
+        }
+        av[q] = va; bv[q] = vb; cv[q] = vc;
+    }
+    const float sy = (Fy & 1) ? 0.f : (float)(s2y / Fy);
+    const bool rank1 = sy != 0.f;
+    // rank-1 term: v[j] = sum_i (-1)^(i-ry) X[i][j]; z = C v
+    if (rank1) {
+        float v = 0.f;
+        if (lane < w)
+            for (int i = 0; i < h; ++i) {
+                const float x = m[(s.y0 + i) * LW + s.x0 + lane];
+                v += ((i - ry) & 1) ? -x : x;
+            }
+        zv[lane] = lane < w ? v : 0.f;
+    }
+    wave_sync();
+    if (rank1) {
+        float z = 0.f;
+        if (lane < w)
+            for (int j2 = 0; j2 < w; ++j2) z += cv[lane + j2] * zv[j2];
+        wave_sync();
+        zv[lane] = z;
+        wave_sync();
+    }
+    const int lr = lane & 15, lq = lane >> 4;
+    // GEMM 1: T = Xw . Hankel(bv), all tiles in registers
+    f32x4 T[4][4];
+#pragma unroll
+    for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) T[tr][tc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < wp; k0 += 4) {
+        const int k = k0 + lq;
+        float a[4], b[4];
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr) {
+            const int i = (tr << 4) + lr;
+            a[tr] = (tr < ntr && i < h && k < w) ? m[(s.y0 + i) * LW + s.x0 + k] : 0.f;
+        }
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) b[tc] = tc < ntc ? bv[k + (tc << 4) + lr] : 0.f;
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr)
+            if (tr < ntr) {
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc)
+                    if (tc < ntc) T[tr][tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tr], b[tc], T[tr][tc], 0, 0, 0);
+            }
+    }
+    // GEMM 2: Y = Hankel(av) . T, one output tile at a time, epilogue in place
+#pragma unroll
+    for (int tr = 0; tr < 4; ++tr) {
+        if (tr >= ntr) continue;
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) {
+            if (tc >= ntc) continue;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk) {
+                if (tk >= ntr) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = av[(tr << 4) + lr + (tk << 4) + 4 * lq + r];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, T[tk][tc][r], acc, 0, 0, 0);
+                }
+            }
+            const int jcol = (tc << 4) + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = (tr << 4) + lq * 4 + r;
+                if (i < h && jcol < w) {
+                    float *p = &m[(s.y0 + i) * LW + s.x0 + jcol];
+                    const float x = *p;
+                    float y2 = acc[r];
+                    if (rank1) y2 += (((i - ry) & 1) ? -sy : sy) * zv[jcol];
+                    *p = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
+                }
+            }
+        }
+    }
+    wave_sync();
+}
+
+__device__ inline void wave_symmetry(const Tile &t, int cy, int cx, int algorithm, float strength,
+                                     double dy, double dx, bool use_fill, float fill, float *vec)
+{
+    const SymWindow s = sym_window(t.H, t.W, cy, cx);
+    if (algorithm == SCARLET_SYM_KSPACE) {
+        if (s.centered) return;
+        wave_kspace_symmetry(t, s, dy, dx, vec);
+    } else {
+        wave_flip_symmetry<float>(t, s, algorithm == SCARLET_SYM_SDSS, strength);
+    }
+    if (use_fill && !s.centered) {
+        for (int i = lane_id(); i < t.H * t.W; i += SC_WAVE) {
+            const int y = i / t.W, x = i - y * t.W;
+            if (y < s.y0 || y >= s.y0 + s.h || x < s.x0 || x >= s.x0 + s.w) t.m[y * t.LW + x] = fill;
+        }
+        wave_sync();
+    }
+}
+
+#define SC_WAVE_VEC_FLOATS 448       // av, bv, cv (128 each) + zv (64)

@@ -1,0 +1,24 @@
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from scarlet_amd import synth
+from scarlet_amd.batch import BlendBatch
+S = 10000
+d = synth.make_batch(0, 512)
+reps = (S + 511) // 512
+imgs = np.tile(d["images"], (reps, 1, 1, 1))[:S]; cen = np.tile(d["centers"], (reps, 1, 1))[:S]
+kw = {}
+if len(sys.argv) > 1 and sys.argv[1] == "nocons": kw = dict(symmetric=False, monotonic=False)
+b = BlendBatch(imgs, cen, **kw)
+b.init_extended(np.ones(5) * .1)
+b.fit(3, e_rel=0, check_every=0)
+torch.cuda.synchronize()
+b.fit(1, e_rel=0, check_every=0)
+torch.cuda.synchronize()
+st = b.workspace[:S * 16 * 8].view(torch.int64).view(S, 16).cpu().numpy()
+dt = np.diff(st[:, :7], axis=1)
+if st[:, 10].any():
+    print("P2 wave0: pre-sym %d  sym %d  sweep %d  tail %d" % ((st[:, 8] - st[:, 4]).mean(), (st[:, 9] - st[:, 8]).mean(),
+          (st[:, 10] - st[:, 9]).mean(), (st[:, 5] - st[:, 10]).mean()))
+print("phase cycles mean:", dt.mean(axis=0).round(0), " total", (st[:, 6] - st[:, 0]).mean())
+print("phase cycles p90 :", np.percentile(dt, 90, axis=0).round(0))
