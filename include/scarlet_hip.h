@@ -52,6 +52,10 @@ extern "C" {
 #define SCARLET_SYM_KSPACE 0
 #define SCARLET_SYM_SOFT   1
 #define SCARLET_SYM_SDSS   2
+/* or-ed into `algorithm`: apply the bare operator to the WHOLE array, symmetric about
+ * index (H/2, W/2) -- operator.prox_soft/sdss/kspace_symmetry called directly -- instead of
+ * going through uncentered_operator's window selection */
+#define SCARLET_SYM_FULL_WINDOW 16
 
 /* normalisation types -- scarlet/update.py:35-68 */
 #define SCARLET_NORM_SED       0
@@ -178,6 +182,11 @@ typedef struct scarlet_batch {
     float l0_thresh, l1_thresh;  /* < 0 -> off; else update.sparse_l0/l1 before positive */
     const double *centroid_psf;  /* [P][P] float64 centroid weight (source.py:483-490) */
     int32_t centroid_P;
+    /* PSF difference kernel of Observation.match (observation.py:191-194), shared by all
+       scenes: [B][psf_h][psf_w] or NULL (render = identity).  When set, call
+       scarlet_batch_prepare_psf() once before fitting (and again if it changes).        */
+    const float *diff_kernel;
+    int32_t psf_h, psf_w;
     /* workspace owned by the caller: scarlet_batch_workspace_bytes() bytes            */
     void *workspace;
 } scarlet_batch;
@@ -222,9 +231,29 @@ int scarlet_profile_end(double total_ms[8], int64_t launches[8]);
  * [B] or NULL), detection coadd, sdss symmetry, thresh=0.1 weighted monotone sweep,
  * cut at bg_cutoff, divide by the centre pixel.  Writes sed/morph of buffer b->cur,
  * flags (NO_VALID_PIXELS when nothing is above the cut), then runs the constraint
- * pipeline once with it=0 as the constructor does (source.py:492).  bg_rms: host [B]. */
+ * pipeline once with it=0 as the constructor does (source.py:492) when run_update != 0.
+ * init_symmetric / init_monotonic: the `symmetric` / `monotonic` arguments of
+ * init_extended_source (ExtendedSource always passes symmetric=True).  bg_rms: host [B]. */
 int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host, float thresh,
-                          const float *sed_scale_host, void *stream);
+                          const float *sed_scale_host, int init_symmetric, int init_monotonic,
+                          int run_update, void *stream);
+
+/* Row a3b set-up: FFT the difference kernel into the workspace (K-hat at the reference's FFT
+ * shape next_fast_len(N + P + 3), fft.py:68-106) and create the batched hipFFT plans (cached
+ * per shape inside the library; the only allocation the library makes). */
+int scarlet_batch_prepare_psf(scarlet_batch *b, void *stream);
+
+/* Observation.render / fft.convolve (observation.py:198-220, fft.py:304-317) for n planes:
+ * out[p] = crop(model[p] (*) kernel[p or 0]) with the reference's pad / shift / crop
+ * conventions.  model, out: device [n][H][W]; kernel: device [nk][Py][Px] with nk == n or 1.
+ * Allocates temporary FFT buffers (set-up / test helper, not on the iteration path). */
+int scarlet_convolve_same(const float *model, int n, int H, int W, const float *kernel, int nk,
+                          int Py, int Px, float *out, void *stream);
+
+/* Convergence sums (blend.py:159-171) of buffer 1-cur vs cur for every component, for
+ * callers that ran their own update() between scarlet_backward_step and
+ * scarlet_check_convergence (scarlet_source_update computes them itself). */
+int scarlet_convergence_sums(scarlet_batch *b, void *stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ OK, E_ARG, E_TOO_LARGE, E_HIP, E_NOTIMPL = 0, -1, -2, -3, -4
 FLAG_SED_NOT_CONVERGED, FLAG_MORPH_NOT_CONVERGED, FLAG_EDGE_PIXELS, FLAG_NO_VALID_PIXELS = 1, 2, 4, 8
 STATUS_CENTER_AT_EDGE, STATUS_NONFINITE = 1, 2
 SYM_KSPACE, SYM_SOFT, SYM_SDSS = 0, 1, 2
+SYM_FULL_WINDOW = 16
 NORM_SED, NORM_MORPH, NORM_MORPH_MAX = 0, 1, 2
 
 
@@ -46,6 +47,7 @@ class ScarletBatch(Structure):
         ("symmetric", c_int32), ("monotonic", c_int32),
         ("l0_thresh", c_float), ("l1_thresh", c_float),
         ("centroid_psf", c_void_p), ("centroid_P", c_int32),
+        ("diff_kernel", c_void_p), ("psf_h", c_int32), ("psf_w", c_int32),
         ("workspace", c_void_p),
     ]
 
@@ -76,7 +78,10 @@ _SIGNATURES = {
     "scarlet_check_convergence": (c_int, [POINTER(ScarletBatch), c_double, _P]),
     "scarlet_profile_begin": (c_int, [c_int]),
     "scarlet_profile_end": (c_int, [_P, _P]),
-    "scarlet_init_extended": (c_int, [POINTER(ScarletBatch), _P, c_float, _P, _P]),
+    "scarlet_init_extended": (c_int, [POINTER(ScarletBatch), _P, c_float, _P, c_int, c_int, c_int, _P]),
+    "scarlet_convergence_sums": (c_int, [POINTER(ScarletBatch), _P]),
+    "scarlet_batch_prepare_psf": (c_int, [POINTER(ScarletBatch), _P]),
+    "scarlet_convolve_same": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -112,8 +112,9 @@ class BlendBatch(object):
     def set_state(self, sed, morph, centers=None, shifts=None):
         """Load factors into the current buffers (e.g. a state produced elsewhere)."""
         t = self.torch
-        sed = t.as_tensor(np.asarray(sed)).to(self.sed[0])
-        morph = t.as_tensor(np.asarray(morph)).to(self.morph[0])
+        as_t = lambda a: a if t.is_tensor(a) else t.as_tensor(np.asarray(a))
+        sed = as_t(sed).to(self.sed[0])
+        morph = as_t(morph).to(self.morph[0])
         for b in range(2):
             self.sed[b].copy_(sed)
             self.morph[b].copy_(morph)
@@ -121,6 +122,22 @@ class BlendBatch(object):
             self.centers.copy_(t.as_tensor(np.asarray(centers)).to(self.centers))
         if shifts is not None:
             self.shifts.copy_(t.as_tensor(np.asarray(shifts, dtype=np.float64)).to(self.shifts))
+
+    def set_diff_kernel(self, kernel):
+        """PSF difference kernel (B, Py, Px) shared by all scenes (what Observation.match
+        computes, reference observation.py:191-194).  Enables the FFT-convolution render
+        (row a3b): grows the workspace by the FFT buffers and transforms the kernel once."""
+        t = self.torch
+        k = (kernel if t.is_tensor(kernel) else t.as_tensor(np.ascontiguousarray(kernel, dtype=np.float32)))
+        self.diff_kernel = k.to(device=self.device, dtype=t.float32).contiguous()
+        assert self.diff_kernel.ndim == 3 and self.diff_kernel.shape[0] == self.B
+        self._c.diff_kernel = self.diff_kernel.data_ptr()
+        self._c.psf_h, self._c.psf_w = int(self.diff_kernel.shape[1]), int(self.diff_kernel.shape[2])
+        nbytes = _lib.lib.scarlet_batch_workspace_bytes(ctypes.byref(self._c))
+        self.workspace = t.zeros((int(nbytes),), dtype=t.uint8, device=self.device)
+        self._c.workspace = self.workspace.data_ptr()
+        _lib.check(_lib.lib.scarlet_batch_prepare_psf(ctypes.byref(self._c), _lib.stream_ptr()))
+        return self
 
     @property
     def sed_current(self):
@@ -143,7 +160,8 @@ class BlendBatch(object):
                              "there too: measurement.py:24-29)".format(bad.tolist()))
 
     # ------------------------------------------------------------------ operations
-    def init_extended(self, bg_rms, thresh=1.0, sed_scale=None):
+    def init_extended(self, bg_rms, thresh=1.0, sed_scale=None, init_symmetric=True, init_monotonic=None,
+                      run_update=True):
         """ExtendedSource initialisation for every component (reference source.py:139-180,
         444-492) followed by the constructor's update() call."""
         bg = np.ascontiguousarray(bg_rms, dtype=np.float32)
@@ -151,7 +169,9 @@ class BlendBatch(object):
         sc = None if sed_scale is None else np.ascontiguousarray(sed_scale, dtype=np.float32)
         rc = _lib.lib.scarlet_init_extended(
             ctypes.byref(self._c), bg.ctypes.data_as(ctypes.c_void_p), float(thresh),
-            None if sc is None else sc.ctypes.data_as(ctypes.c_void_p), _lib.stream_ptr())
+            None if sc is None else sc.ctypes.data_as(ctypes.c_void_p), int(bool(init_symmetric)),
+            int(self.monotonic if init_monotonic is None else bool(init_monotonic)), int(bool(run_update)),
+            _lib.stream_ptr())
         _lib.check(rc)
         return self
 

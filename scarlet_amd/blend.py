@@ -1,0 +1,191 @@
+"""The blended scene and its proximal-gradient fit (reference ``scarlet/blend.py`` API).
+
+``Blend(sources, observations).fit(max_iter, e_rel, approximate_L)`` runs the reference's
+iteration (blend.py:65-102) on the GPU.  A `Blend` is a batch of ONE scene on top of
+`scarlet_amd.batch.BlendBatch`; many scenes at once go through `BlendBatch` directly.
+
+Two execution modes, chosen automatically:
+
+* built-in pipeline: every source is a `PointSource`/`ExtendedSource` whose ``update`` is not
+  overridden -> the whole fit stays on the device (fused kernels, no per-iteration sync);
+* Python pipeline: some source overrides ``update()`` (the reference's extension point,
+  component.py:189-196) or is a plain `Component` -> per iteration the gradient step runs on
+  the device, then each source's Python ``update()`` (whose `update.*`/`operator.*` calls are
+  HIP kernels on the same device memory), then the device convergence check.
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from . import _lib
+from .component import ComponentTree, BlendFlag
+
+logger = logging.getLogger("scarlet_amd.blend")
+
+
+def render_with_kernel(model, kernel_image):
+    """Observation.render's convolution (reference observation.py:198-201) on the device."""
+    from .psfconv import convolve_same
+    return convolve_same(model, kernel_image)
+
+
+class Blend(ComponentTree):
+    """The blended scene (reference blend.py:11-63).
+
+    Attributes: ``mse`` (loss before each step), ``it``, ``converged``, ``observations``.
+    """
+
+    def __init__(self, sources, observations):
+        ComponentTree.__init__(self, sources)
+        try:
+            iter(observations)
+        except TypeError:
+            observations = (observations,)
+        self.observations = tuple(observations)
+        self._batch = None
+        self._view_buf = 0            # which ping-pong buffer the component views show
+        self.L_sed = 1
+        self.L_morph = 1
+
+    # ------------------------------------------------------------------ device state
+    def _source_attr(self, name, default):
+        vals = [getattr(s, name, default) for s in self.sources]
+        return vals
+
+    def _builtin_pipeline(self):
+        """True when every source uses the reference's stock update() (source.py:402-440)."""
+        from .source import PointSource
+        for s in self.sources:
+            if not isinstance(s, PointSource) or type(s).update is not PointSource.update:
+                return False
+            if getattr(s, "prior", None) is not None or hasattr(s, "bboxes"):
+                return False
+        sym = {bool(s.symmetric) for s in self.sources}
+        mono = {bool(s.monotonic) for s in self.sources}
+        return len(sym) == 1 and len(mono) == 1
+
+    def _ensure_batch(self):
+        if self._batch is not None:
+            return self._batch
+        torch = _lib.require_gpu()
+        from .batch import BlendBatch
+        if len(self.observations) != 1:
+            raise NotImplementedError("fits with several observations are not supported yet "
+                                      "(SURVEY.md 8f rank 4)")
+        obs = self.observations[0]
+        if obs._band_slice != slice(None):
+            raise NotImplementedError("band-sliced observations are not supported yet")
+        comps = self.components
+        centers = []
+        for c in comps:
+            pc = getattr(c, "pixel_center", None)
+            if pc is None:
+                pc = (self.frame.Ny // 2, self.frame.Nx // 2)
+            centers.append((int(pc[0]), int(pc[1])))
+        cw = None
+        for s in self.sources:
+            if getattr(s, "_centroid_weight", None) is not None:
+                cw = np.asarray(s._centroid_weight, dtype=np.float64)
+                break
+        builtin = self._builtin_pipeline()
+        b = BlendBatch(obs._images_device()[None], np.array(centers, dtype=np.int32)[None],
+                       weights=None if obs._weights_device() is None else obs._weights_device()[None],
+                       symmetric=bool(self.sources[0].symmetric) if builtin else False,
+                       monotonic=bool(self.sources[0].monotonic) if builtin else False,
+                       centroid_weight=cw)
+        if type(obs.weights) is not np.ndarray and obs.weights != 1:
+            b._c.weight_scalar = float(obs.weights)
+        if obs._diff_kernels is not None:
+            b.set_diff_kernel(np.asarray(obs._diff_kernels.image, dtype=np.float32))
+        sed = torch.stack([c._own_sed for c in comps])[None]
+        morph = torch.stack([c._own_morph for c in comps])[None]
+        shifts = np.full((1, len(comps), 2), np.nan)
+        for k, c in enumerate(comps):
+            sh = getattr(c, "shift", None)
+            if sh is not None:
+                shifts[0, k] = (float(sh[0]), float(sh[1]))
+        b.set_state(sed, morph, shifts=shifts)
+        if any(c.fix_sed for c in comps) or any(c.fix_morph for c in comps):
+            b.fix_sed = torch.tensor([[int(bool(c.fix_sed)) for c in comps]], dtype=torch.uint8, device="cuda")
+            b.fix_morph = torch.tensor([[int(bool(c.fix_morph)) for c in comps]], dtype=torch.uint8, device="cuda")
+            b._fill_struct()
+        b.flags[0] = torch.tensor([c._flags.value for c in comps], dtype=torch.int32, device="cuda")
+        self._batch = b
+        self._view_buf = 0
+        for k, c in enumerate(comps):
+            c._binding = (self, k)
+        return b
+
+    def _factor_view(self, which, k):
+        pair = self._batch.sed if which == "sed" else self._batch.morph
+        return pair[self._view_buf][0, k]
+
+    def _sync_sources(self):
+        """Copy per-component scalars the device updated back to the Python objects."""
+        b = self._batch
+        self._view_buf = int(b.cur[0].item())
+        cen = b.centers[0].cpu().numpy()
+        sh = b.shifts[0].cpu().numpy()
+        L = b.lipschitz[0].cpu().numpy()
+        self.L_sed, self.L_morph = float(L[0]), float(L[1])
+        for k, c in enumerate(self.components):
+            c.L_sed, c.L_morph = self.L_sed, self.L_morph
+            if hasattr(c, "pixel_center"):
+                c.pixel_center = (int(cen[k, 0]), int(cen[k, 1]))
+                if not np.isnan(sh[k, 0]):
+                    c.shift = (float(sh[k, 0]), float(sh[k, 1]))
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def mse(self):
+        """Loss before each iteration's step (reference blend.py:138)."""
+        return [] if self._batch is None else self._batch.mse(0)
+
+    @property
+    def it(self):
+        """Number of iterations run so far (= len(mse); inside a source's update() it already
+        counts the iteration in progress, as in the reference where _backward appended first)."""
+        if hasattr(self, "_it_in_progress"):
+            return self._it_in_progress
+        return 0 if self._batch is None else int(self._batch.it[0].item())
+
+    @property
+    def converged(self):
+        for c in self.components:
+            if (c.flags & (BlendFlag.SED_NOT_CONVERGED | BlendFlag.MORPH_NOT_CONVERGED)).value > 0:
+                return False
+        return True
+
+    def fit(self, max_iter=200, e_rel=1e-2, approximate_L=False):
+        """Fit the model of every source to the data (reference blend.py:65-102)."""
+        b = self._ensure_batch()
+        if self._builtin_pipeline():
+            b.fit(max_iter, e_rel=e_rel, approximate_L=approximate_L, check_every=4)
+            b.raise_on_status()
+            self._sync_sources()
+            return self
+        # Python pipeline: device gradient step, Python update() per source, device check
+        s = _lib.stream_ptr
+        b._ensure_mse_capacity(max_iter)
+        b.active.fill_(1)
+        for _ in range(max_iter):
+            for c in self.components:
+                if c.prior is not None:
+                    raise NotImplementedError("Prior hooks are not supported yet (SURVEY.md 8f rank 3)")
+            _lib.check(_lib.lib.scarlet_backward_step(ctypes.byref(b._c), int(bool(approximate_L)), s()))
+            cur = int(b.cur[0].item())
+            self._view_buf = 1 - cur                     # sources see the stepped factors
+            L = b.lipschitz[0].cpu().numpy()
+            self.L_sed, self.L_morph = float(L[0]), float(L[1])
+            for c in self.components:
+                c.L_sed, c.L_morph = self.L_sed, self.L_morph
+            self._it_in_progress = int(b.it[0].item()) + 1
+            self.update()
+            del self._it_in_progress
+            _lib.check(_lib.lib.scarlet_convergence_sums(ctypes.byref(b._c), s()))
+            _lib.check(_lib.lib.scarlet_check_convergence(ctypes.byref(b._c), float(e_rel), s()))
+            self._view_buf = int(b.cur[0].item())
+            if int(b.active[0].item()) == 0:
+                break
+        return self

@@ -362,7 +362,11 @@ __device__ inline void symmetry_tile(const Tile &t, int cy, int cx, int algorith
                                      float fill, float *scr, float *av, float *bv, float *cv,
                                      float *zv)
 {
-    const SymWindow s = sym_window(t.H, t.W, cy, cx);
+    SymWindow s = sym_window(t.H, t.W, cy, cx);
+    if (algorithm & SCARLET_SYM_FULL_WINDOW) {   // bare operator on the whole array (operator.py:231-288)
+        algorithm &= ~SCARLET_SYM_FULL_WINDOW;
+        s.y0 = 0; s.x0 = 0; s.h = t.H; s.w = t.W; s.centered = false;
+    }
     if (algorithm == SCARLET_SYM_KSPACE) {
         if (s.centered) return;          // Appendix A.1: result discarded by the reference
         kspace_symmetry_tile(t, s, dy, dx, scr, av, bv, cv, zv);

@@ -1,0 +1,318 @@
+// psf_path.h -- row a3b: Observation.render with a PSF difference kernel, and its adjoint.
+//
+// The reference renders a model by zero-pad -> ifftshift -> rfftn -> * K-hat -> irfftn ->
+// fftshift -> centre crop (observation.py:198-201, fft.py:304-317, 264-279, 193-211,
+// 138-181, 38-65, 7-35, 68-106) at the 5-smooth FFT shape of (N + P + 3) per axis (last axis
+// even), and autograd runs the same chain with conj(K-hat) for the gradient.  With the pad
+// start (dS+1)//2, the shift F//2 and the crop start (cur-new+1)//2 all three index maps
+// collapse to ONE modular offset per array:
+//     image pixel y  <->  padded, shifted index  (y + o_img) mod F,   o_img = (F-N+1)//2 - F//2
+//     kernel pixel q <->                         (q + o_ker) mod F,   o_ker = (F-P+1)//2 - F//2
+// so the kernels below read/write the FFT buffers directly at those indices -- no separate
+// pad / shift / crop passes.  The transforms themselves are batched hipFFT (rocFFT) R2C / C2R
+// plans over all (scene, band) planes; K-hat is computed once per batch.
+//
+// One iteration with a PSF:
+//   k_psf_model   : model planes written at their padded positions (zeros elsewhere)
+//   R2C, k_spec_mul (K-hat, 1/F scaling), C2R
+//   k_psf_resid   : d = w (render - image), loss partials; writes w d back at padded positions
+//   R2C, k_spec_mul (conj K-hat), C2R          -> G = render^T (w d)
+//   k_grad_psf / k_step_psf : as k_grad / k_step but with G read from the FFT buffer
+#pragma once
+#include "common.h"
+#include "engine.h"
+
+struct PsfGeom {
+    int H, W, Fy, Fx, Fxh;       // Fxh = Fx/2 + 1
+    int oy, ox;                  // image offsets (mod F)
+};
+
+__host__ __device__ inline int pos_mod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
+
+struct PsfArgs {
+    int S, K, B, T;
+    PsfGeom g;
+    const float *images, *weights;
+    float weight_scalar;
+    float *sed[2], *morph[2];
+    const int *cur;
+    const uint8_t *fix_sed, *fix_morph;
+    float *real;                 // [S*B][Fy][Fx]
+    float2 *spec;                // [S*B][Fy][Fxh]
+    const float2 *khat;          // [B][Fy][Fxh]
+    double *partials;            // [S][T][P] (sed gradient + Gram) ; loss in loss_part
+    double *loss_part;           // [S][B]
+    double *lipschitz, *mse;
+    int mse_capacity;
+    int *it;
+    const int *active;
+    int approximate_L;
+};
+
+// model_b = sum_k sed[k][b] morph[k] written into the padded FFT input plane (a1, a2 + pad)
+__global__ __launch_bounds__(SC_BLOCK) void k_psf_model(PsfArgs a)
+{
+    const int plane = blockIdx.y, s = plane / a.B, b = plane - s * a.B;
+    if (!a.active[s]) return;
+    const PsfGeom g = a.g;
+    const int c0 = a.cur[s], HW = g.H * g.W;
+    __shared__ float sed_s[SC_KMAX];
+    if (threadIdx.x < a.K) sed_s[threadIdx.x] = a.sed[c0][((size_t)s * a.K + threadIdx.x) * a.B + b];
+    __syncthreads();
+    const float *mor = a.morph[c0] + (size_t)s * a.K * HW;
+    float *out = a.real + (size_t)plane * g.Fy * g.Fx;
+    const int n = g.Fy * g.Fx;
+    for (int i = blockIdx.x * SC_BLOCK + threadIdx.x; i < n; i += gridDim.x * SC_BLOCK) {
+        const int iy = i / g.Fx, ix = i - iy * g.Fx;
+        const int y = pos_mod(iy - g.oy, g.Fy), x = pos_mod(ix - g.ox, g.Fx);
+        float v = 0.f;
+        if (y < g.H && x < g.W)
+            for (int k = 0; k < a.K; ++k) v += sed_s[k] * mor[(size_t)k * HW + y * g.W + x];
+        out[i] = v;
+    }
+}
+
+// spectrum *= K-hat (or its conjugate) * scale ; K-hat is shared by all scenes of a band
+__global__ void k_spec_mul(float2 *spec, const float2 *khat, int B, int plane_elems, int64_t total,
+                           int conj, float scale)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int plane = (int)(i / plane_elems), e = (int)(i - (int64_t)plane * plane_elems);
+        const float2 k = khat[(size_t)(plane % B) * plane_elems + e];
+        const float2 v = spec[i];
+        const float ki = conj ? -k.y : k.y;
+        spec[i] = make_float2((v.x * k.x - v.y * ki) * scale, (v.x * ki + v.y * k.x) * scale);
+    }
+}
+
+// d = w (render - image); loss; w d written back (padded layout, zeros outside the image)
+__global__ __launch_bounds__(SC_BLOCK) void k_psf_resid(PsfArgs a)
+{
+    const int plane = blockIdx.x, s = plane / a.B, b = plane - s * a.B;
+    if (!a.active[s]) return;
+    const PsfGeom g = a.g;
+    __shared__ double red[SC_NWAVES];
+    const int HW = g.H * g.W;
+    float *buf = a.real + (size_t)plane * g.Fy * g.Fx;
+    const float *img = a.images + ((size_t)s * a.B + b) * HW;
+    const float *wgt = a.weights ? a.weights + ((size_t)s * a.B + b) * HW : nullptr;
+    const int n = g.Fy * g.Fx;
+    double loss = 0;
+    for (int i = threadIdx.x; i < n; i += SC_BLOCK) {
+        const int iy = i / g.Fx, ix = i - iy * g.Fx;
+        const int y = pos_mod(iy - g.oy, g.Fy), x = pos_mod(ix - g.ox, g.Fx);
+        float v = 0.f;
+        if (y < g.H && x < g.W) {
+            const float w = wgt ? wgt[y * g.W + x] : a.weight_scalar;
+            const float d = w * (buf[i] - img[y * g.W + x]);
+            loss += (double)d * (double)d;
+            v = w * d;
+        }
+        buf[i] = v;
+    }
+    loss = block_sum(loss, red);
+    if (threadIdx.x == 0) a.loss_part[plane] = 0.5 * loss;
+}
+
+// G (B planes, padded layout) -> partial sums of d loss / d sed and of the morph Gram
+template <int KM, int BM>
+__global__ __launch_bounds__(SC_BLOCK) void k_grad_psf(PsfArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const PsfGeom g = a.g;
+    const int K = a.K, B = a.B, HW = g.H * g.W;
+    __shared__ double red[SC_NWAVES][KM * BM + KM * (KM + 1) / 2];
+    const int c0 = a.cur[s];
+    float dsed[KM][BM], gram[KM * (KM + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b) dsed[k][b] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KM * (KM + 1) / 2; ++i) gram[i] = 0.f;
+    const float *mor = a.morph[c0] + (size_t)s * K * HW;
+    const float *G = a.real + (size_t)s * B * g.Fy * g.Fx;
+    const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
+        const int y = p / g.W, x = p - y * g.W;
+        const int gi0 = pos_mod(y + g.oy, g.Fy) * g.Fx + pos_mod(x + g.ox, g.Fx);
+        float m[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) m[k] = k < K ? mor[(size_t)k * HW + p] : 0.f;
+#pragma unroll
+        for (int b = 0; b < BM; ++b)
+            if (b < B) {
+                const float gg = G[(size_t)b * g.Fy * g.Fx + gi0];
+#pragma unroll
+                for (int k = 0; k < KM; ++k) dsed[k][b] += gg * m[k];
+            }
+        int gi = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < KM; ++k2) gram[gi++] += m[k] * m[k2];
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b)
+            if (k < K && b < B) {
+                const double v = wave_sum((double)dsed[k][b]);
+                if (lane == 0) red[wid][k * B + b] = v;
+            }
+    {
+        int gi = 0, go = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < KM; ++k2) {
+                if (k < K && k2 < K) {
+                    const double v = wave_sum((double)gram[gi]);
+                    if (lane == 0) red[wid][K * B + go] = v;
+                    ++go;
+                }
+                ++gi;
+            }
+    }
+    __syncthreads();
+    const int P = n_partials(K, B);
+    double *out = a.partials + ((size_t)s * a.T + tile) * P;
+    for (int i = threadIdx.x; i < P - 1; i += SC_BLOCK) {
+        double r = 0;
+#pragma unroll
+        for (int w = 0; w < SC_NWAVES; ++w) r += red[w][i];
+        out[1 + i] = r;
+    }
+    if (threadIdx.x == 0) {
+        // the loss of the scene (sum over its bands) rides in slot 0 of tile 0
+        double l = 0;
+        if (tile == 0) for (int b = 0; b < B; ++b) l += a.loss_part[s * B + b];
+        out[0] = l;
+    }
+}
+
+// Lipschitz constants + SED step + morphology step from G (same bookkeeping as k_step)
+template <int KM, int BM>
+__global__ __launch_bounds__(SC_BLOCK) void k_step_psf(PsfArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const PsfGeom g = a.g;
+    const int K = a.K, B = a.B, HW = g.H * g.W, P = n_partials(K, B);
+    __shared__ double tot[1 + KM * BM + KM * (KM + 1) / 2];
+    __shared__ double mat[KM * KM + BM * BM];
+    __shared__ float sed_s[KM * BM];
+    __shared__ float step_s[2];
+    for (int i = threadIdx.x; i < P; i += SC_BLOCK) {
+        double r = 0;
+        for (int t = 0; t < a.T; ++t) r += a.partials[((size_t)s * a.T + t) * P + i];
+        tot[i] = r;
+    }
+    const int c0 = a.cur[s];
+    const float *sed_in = a.sed[c0];
+    float *sed_out = a.sed[1 - c0];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
+        sed_s[(i / B) * BM + (i % B)] = sed_in[(size_t)s * K * B + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int it_new = a.it[s] + 1;
+        const double loss = tot[0];
+        double L_sed, L_morph;
+        if (a.approximate_L) {
+            double LA = 0, LS = 0;
+            int go = 0;
+            for (int k = 0; k < K; ++k)
+                for (int k2 = k; k2 < K; ++k2) { if (k2 == k) LA += tot[1 + K * B + go]; ++go; }
+            for (int k = 0; k < K; ++k)
+                for (int b = 0; b < B; ++b) LS += (double)sed_s[k * BM + b] * sed_s[k * BM + b];
+            if (it_new > 1 && loss > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { LA *= 2; LS *= 2; }
+            L_sed = LA; L_morph = LS;
+        } else {
+            double *Gm = mat, *ATA = mat + KM * KM;
+            int go = 0;
+            for (int k = 0; k < K; ++k)
+                for (int k2 = k; k2 < K; ++k2) { Gm[k * KM + k2] = Gm[k2 * KM + k] = tot[1 + K * B + go]; ++go; }
+            for (int b = 0; b < B; ++b)
+                for (int b2 = 0; b2 < B; ++b2) {
+                    double r = 0;
+                    for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
+                    ATA[b * BM + b2] = r;
+                }
+            L_sed = jacobi_lambda_max(Gm, K, KM);
+            L_morph = jacobi_lambda_max(ATA, B, BM);
+        }
+        step_s[0] = 1.0f / (float)L_sed;
+        step_s[1] = 1.0f / (float)L_morph;
+        if (tile == 0) {
+            if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
+            a.lipschitz[2 * s] = L_sed;
+            a.lipschitz[2 * s + 1] = L_morph;
+        }
+    }
+    __syncthreads();
+    const float step_sed = step_s[0], step_morph = step_s[1];
+    if (tile == 0)
+        for (int i = threadIdx.x; i < K * B; i += SC_BLOCK) {
+            const int k = i / B;
+            const float curv = sed_s[k * BM + (i % B)];
+            const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + k];
+            sed_out[(size_t)s * K * B + i] = fixed ? curv : curv - step_sed * (float)tot[1 + i];
+        }
+    const float *mor = a.morph[c0] + (size_t)s * K * HW;
+    float *mout = a.morph[1 - c0] + (size_t)s * K * HW;
+    const float *G = a.real + (size_t)s * B * g.Fy * g.Fx;
+    const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
+        const int y = p / g.W, x = p - y * g.W;
+        const int gi0 = pos_mod(y + g.oy, g.Fy) * g.Fx + pos_mod(x + g.ox, g.Fx);
+        float gb[BM];
+#pragma unroll
+        for (int b = 0; b < BM; ++b) gb[b] = b < B ? G[(size_t)b * g.Fy * g.Fx + gi0] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < K) {
+                const float m = mor[(size_t)k * HW + p];
+                float gm = 0.f;
+#pragma unroll
+                for (int b = 0; b < BM; ++b) gm += sed_s[k * BM + b] * gb[b];
+                const bool fixed = a.fix_morph && a.fix_morph[(size_t)s * K + k];
+                mout[(size_t)k * HW + p] = fixed ? m : m - step_morph * gm;
+            }
+    }
+}
+
+// kernel image [B][Py][Px] -> padded, shifted FFT input planes [B][Fy][Fx]
+__global__ void k_psf_pad_kernel(const float *ker, int B, int Py, int Px, int Fy, int Fx, int oky, int okx,
+                                 float *out)
+{
+    const int64_t total = (int64_t)B * Fy * Fx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / ((int64_t)Fy * Fx)), e = (int)(i - (int64_t)b * Fy * Fx);
+        const int iy = e / Fx, ix = e - iy * Fx;
+        const int q = pos_mod(iy - oky, Fy), r = pos_mod(ix - okx, Fx);
+        out[i] = (q < Py && r < Px) ? ker[((size_t)b * Py + q) * Px + r] : 0.f;
+    }
+}
+
+// generic plane pad / crop for the standalone render (Observation.render)
+__global__ void k_plane_pad(const float *in, int n, int H, int W, int Fy, int Fx, int oy, int ox, float *out)
+{
+    const int64_t total = (int64_t)n * Fy * Fx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / ((int64_t)Fy * Fx)), e = (int)(i - (int64_t)p * Fy * Fx);
+        const int iy = e / Fx, ix = e - iy * Fx;
+        const int y = pos_mod(iy - oy, Fy), x = pos_mod(ix - ox, Fx);
+        out[i] = (y < H && x < W) ? in[((size_t)p * H + y) * W + x] : 0.f;
+    }
+}
+__global__ void k_plane_crop(const float *in, int n, int H, int W, int Fy, int Fx, int oy, int ox, float *out)
+{
+    const int64_t total = (int64_t)n * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / ((int64_t)H * W)), e = (int)(i - (int64_t)p * H * W);
+        const int y = e / W, x = e - y * W;
+        out[i] = in[((size_t)p * Fy + pos_mod(y + oy, Fy)) * Fx + pos_mod(x + ox, Fx)];
+    }
+}

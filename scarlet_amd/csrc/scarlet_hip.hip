@@ -6,12 +6,16 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <map>
+#include <tuple>
 #include <vector>
+#include <hipfft/hipfft.h>
 
 #include "common.h"
 #include "prox_ops.h"
 #include "engine.h"
 #include "fused.h"
+#include "psf_path.h"
 
 __constant__ unsigned short sc_nfl_table[SC_NFL_MAX];
 
@@ -231,8 +235,9 @@ extern "C" int scarlet_prox_symmetry(float *x, int n, int H, int W, const int32_
                                      const double *shifts, int algorithm, float strength,
                                      int use_fill, float fill, void *stream)
 {
-    if (algorithm < 0 || algorithm > 2) return set_err(SCARLET_E_ARG, "algorithm must be one of 'soft', 'sdss', 'kspace'");
-    if (algorithm == SCARLET_SYM_KSPACE && !shifts) return set_err(SCARLET_E_ARG, "kspace symmetry needs shifts");
+    const int base_alg = algorithm & ~SCARLET_SYM_FULL_WINDOW;
+    if (base_alg < 0 || base_alg > 2) return set_err(SCARLET_E_ARG, "algorithm must be one of 'soft', 'sdss', 'kspace'");
+    if (base_alg == SCARLET_SYM_KSPACE && !shifts) return set_err(SCARLET_E_ARG, "kspace symmetry needs shifts");
     OpArgs a = {};
     a.x = x; a.n = n; a.H = H; a.W = W; a.centers = (int *)centers; a.shifts = (double *)shifts;
     a.op = OP_SYMMETRY; a.algorithm = algorithm; a.strength = strength; a.use_fill = use_fill; a.fill = fill;
@@ -538,11 +543,44 @@ static int check_batch(const scarlet_batch *b)
 
 static int n_tiles(const scarlet_batch *b) { return (b->H * b->W + SC_TILE_PIX - 1) / SC_TILE_PIX; }
 
+// ---- PSF path geometry (fft.py:68-106: next_fast_len(N + P + 3) per axis, last axis even)
+static PsfGeom psf_geom(int H, int W, int Py, int Px)
+{
+    PsfGeom g;
+    g.H = H; g.W = W;
+    g.Fy = scarlet_next_fast_len(H + Py + 3);
+    g.Fx = scarlet_next_fast_len(W + Px + 3);
+    while (g.Fx & 1) g.Fx = scarlet_next_fast_len(g.Fx + 1);
+    g.Fxh = g.Fx / 2 + 1;
+    g.oy = (g.Fy - H + 1) / 2 - g.Fy / 2;
+    g.ox = (g.Fx - W + 1) / 2 - g.Fx / 2;
+    return g;
+}
+static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+static int64_t base_workspace_bytes(const scarlet_batch *b)
+{
+    const int64_t P = n_partials(b->K, b->B);
+    return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4) + 256);
+}
+struct PsfLayout { int64_t loss, real, spec, khat, total; };
+static PsfLayout psf_layout(const scarlet_batch *b)
+{
+    const PsfGeom g = psf_geom(b->H, b->W, b->psf_h, b->psf_w);
+    const int64_t planes = (int64_t)b->S * b->B;
+    PsfLayout l;
+    l.loss = base_workspace_bytes(b);
+    l.real = l.loss + align256(planes * (int64_t)sizeof(double));
+    l.spec = l.real + align256(planes * g.Fy * g.Fx * (int64_t)sizeof(float));
+    l.khat = l.spec + align256(planes * g.Fy * g.Fxh * (int64_t)sizeof(float2));
+    l.total = l.khat + align256((int64_t)b->B * g.Fy * g.Fxh * (int64_t)sizeof(float2));
+    return l;
+}
+
 extern "C" int64_t scarlet_batch_workspace_bytes(const scarlet_batch *b)
 {
     if (!b) return 0;
-    const int64_t P = n_partials(b->K, b->B);
-    return sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4) + 256;
+    if (b->diff_kernel && b->psf_h > 0 && b->psf_w > 0) return psf_layout(b).total;
+    return base_workspace_bytes(b);
 }
 
 static double *ws_partials(const scarlet_batch *b) { return (double *)b->workspace; }
@@ -563,10 +601,151 @@ static GradArgs grad_args(const scarlet_batch *b, int approximate_L)
     return a;
 }
 
+// ---- hipFFT plan cache: one (R2C, C2R) pair per (Fy, Fx, batch)
+struct FftPlans { hipfftHandle r2c, c2r; };
+static std::map<std::tuple<int, int, int>, FftPlans> g_plans;
+static int get_plans(int Fy, int Fx, int batch, FftPlans *out)
+{
+    auto key = std::make_tuple(Fy, Fx, batch);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        FftPlans p;
+        int n[2] = {Fy, Fx};
+        if (hipfftPlanMany(&p.r2c, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_R2C, batch) != HIPFFT_SUCCESS ||
+            hipfftPlanMany(&p.c2r, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, batch) != HIPFFT_SUCCESS)
+            return set_err(SCARLET_E_HIP, "hipfftPlanMany failed");
+        it = g_plans.emplace(key, p).first;
+    }
+    *out = it->second;
+    return SCARLET_OK;
+}
+static int fft_r2c(const FftPlans &p, float *in, float2 *out, hipStream_t st)
+{
+    if (hipfftSetStream(p.r2c, st) != HIPFFT_SUCCESS ||
+        hipfftExecR2C(p.r2c, (hipfftReal *)in, (hipfftComplex *)out) != HIPFFT_SUCCESS)
+        return set_err(SCARLET_E_HIP, "hipfftExecR2C failed");
+    return SCARLET_OK;
+}
+static int fft_c2r(const FftPlans &p, float2 *in, float *out, hipStream_t st)
+{
+    if (hipfftSetStream(p.c2r, st) != HIPFFT_SUCCESS ||
+        hipfftExecC2R(p.c2r, (hipfftComplex *)in, (hipfftReal *)out) != HIPFFT_SUCCESS)
+        return set_err(SCARLET_E_HIP, "hipfftExecC2R failed");
+    return SCARLET_OK;
+}
+static unsigned grid_for(int64_t n) { int64_t g = (n + SC_BLOCK - 1) / SC_BLOCK; return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+extern "C" int scarlet_batch_prepare_psf(scarlet_batch *b, void *stream)
+{
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!b->diff_kernel || b->psf_h <= 0 || b->psf_w <= 0) return set_err(SCARLET_E_ARG, "no diff_kernel in batch");
+    const PsfGeom g = psf_geom(b->H, b->W, b->psf_h, b->psf_w);
+    const PsfLayout l = psf_layout(b);
+    hipStream_t st = (hipStream_t)stream;
+    float *real = (float *)((char *)b->workspace + l.real);
+    float2 *khat = (float2 *)((char *)b->workspace + l.khat);
+    const int oky = (g.Fy - b->psf_h + 1) / 2 - g.Fy / 2, okx = (g.Fx - b->psf_w + 1) / 2 - g.Fx / 2;
+    hipLaunchKernelGGL(k_psf_pad_kernel, dim3(grid_for((int64_t)b->B * g.Fy * g.Fx)), dim3(SC_BLOCK), 0, st,
+                       b->diff_kernel, b->B, b->psf_h, b->psf_w, g.Fy, g.Fx, oky, okx, real);
+    FftPlans pk;
+    if ((rc = get_plans(g.Fy, g.Fx, b->B, &pk))) return rc;
+    if ((rc = fft_r2c(pk, real, khat, st))) return rc;
+    FftPlans pb;
+    if ((rc = get_plans(g.Fy, g.Fx, b->S * b->B, &pb))) return rc;     // create the big plans now
+    HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
+}
+
+static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
+{
+    const PsfGeom g = psf_geom(b->H, b->W, b->psf_h, b->psf_w);
+    const PsfLayout l = psf_layout(b);
+    hipStream_t st = (hipStream_t)stream;
+    PsfArgs a;
+    a.S = b->S; a.K = b->K; a.B = b->B; a.T = n_tiles(b); a.g = g;
+    a.images = b->images; a.weights = b->weights; a.weight_scalar = b->weight_scalar;
+    a.sed[0] = b->sed[0]; a.sed[1] = b->sed[1]; a.morph[0] = b->morph[0]; a.morph[1] = b->morph[1];
+    a.cur = b->cur; a.fix_sed = b->fix_sed; a.fix_morph = b->fix_morph;
+    a.real = (float *)((char *)b->workspace + l.real);
+    a.spec = (float2 *)((char *)b->workspace + l.spec);
+    a.khat = (const float2 *)((char *)b->workspace + l.khat);
+    a.partials = ws_partials(b); a.loss_part = (double *)((char *)b->workspace + l.loss);
+    a.lipschitz = b->lipschitz; a.mse = b->mse; a.mse_capacity = b->mse_capacity;
+    a.it = b->it; a.active = b->active; a.approximate_L = approximate_L;
+    const int planes = b->S * b->B;
+    const int plane_elems = g.Fy * g.Fxh;
+    const float scale = 1.0f / ((float)g.Fy * (float)g.Fx);
+    FftPlans p;
+    int rc = get_plans(g.Fy, g.Fx, planes, &p);
+    if (rc) return rc;
+    prof_start(5, st);
+    hipLaunchKernelGGL(k_psf_model, dim3(grid_for((int64_t)g.Fy * g.Fx), planes), dim3(SC_BLOCK), 0, st, a);
+    if ((rc = fft_r2c(p, a.real, a.spec, st))) return rc;
+    hipLaunchKernelGGL(k_spec_mul, dim3(grid_for((int64_t)planes * plane_elems)), dim3(SC_BLOCK), 0, st,
+                       a.spec, a.khat, b->B, plane_elems, (int64_t)planes * plane_elems, 0, scale);
+    if ((rc = fft_c2r(p, a.spec, a.real, st))) return rc;
+    hipLaunchKernelGGL(k_psf_resid, dim3(planes), dim3(SC_BLOCK), 0, st, a);
+    if ((rc = fft_r2c(p, a.real, a.spec, st))) return rc;
+    hipLaunchKernelGGL(k_spec_mul, dim3(grid_for((int64_t)planes * plane_elems)), dim3(SC_BLOCK), 0, st,
+                       a.spec, a.khat, b->B, plane_elems, (int64_t)planes * plane_elems, 1, scale);
+    if ((rc = fft_c2r(p, a.spec, a.real, st))) return rc;
+    prof_stop(st);
+    dim3 grid(a.T, a.S);
+    if (b->K <= 4) {
+        prof_start(0, st);
+        hipLaunchKernelGGL((k_grad_psf<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_stop(st); prof_start(1, st);
+        hipLaunchKernelGGL((k_step_psf<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_stop(st);
+    } else {
+        prof_start(0, st);
+        hipLaunchKernelGGL((k_grad_psf<SC_KMAX, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_stop(st); prof_start(1, st);
+        hipLaunchKernelGGL((k_step_psf<SC_KMAX, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_stop(st);
+    }
+    HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
+}
+
+extern "C" int scarlet_convolve_same(const float *model, int n, int H, int W, const float *kernel, int nk,
+                                     int Py, int Px, float *out, void *stream)
+{
+    if (!model || !kernel || !out || n <= 0 || H <= 0 || W <= 0 || Py <= 0 || Px <= 0 || (nk != n && nk != 1))
+        return set_err(SCARLET_E_ARG, "bad convolve arguments");
+    const PsfGeom g = psf_geom(H, W, Py, Px);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t plane = (int64_t)g.Fy * g.Fx, splane = (int64_t)g.Fy * g.Fxh;
+    float *real = nullptr, *kreal = nullptr; float2 *spec = nullptr, *kspec = nullptr;
+    HIP_TRY(hipMalloc((void **)&real, n * plane * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&kreal, nk * plane * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&spec, n * splane * sizeof(float2)));
+    HIP_TRY(hipMalloc((void **)&kspec, nk * splane * sizeof(float2)));
+    const int oky = (g.Fy - Py + 1) / 2 - g.Fy / 2, okx = (g.Fx - Px + 1) / 2 - g.Fx / 2;
+    hipLaunchKernelGGL(k_plane_pad, dim3(grid_for(n * plane)), dim3(SC_BLOCK), 0, st, model, n, H, W, g.Fy, g.Fx, g.oy, g.ox, real);
+    hipLaunchKernelGGL(k_psf_pad_kernel, dim3(grid_for(nk * plane)), dim3(SC_BLOCK), 0, st, kernel, nk, Py, Px, g.Fy, g.Fx, oky, okx, kreal);
+    FftPlans pm, pk;
+    int rc;
+    if ((rc = get_plans(g.Fy, g.Fx, n, &pm))) return rc;
+    if ((rc = get_plans(g.Fy, g.Fx, nk, &pk))) return rc;
+    if ((rc = fft_r2c(pm, real, spec, st))) return rc;
+    if ((rc = fft_r2c(pk, kreal, kspec, st))) return rc;
+    hipLaunchKernelGGL(k_spec_mul, dim3(grid_for(n * splane)), dim3(SC_BLOCK), 0, st, spec, kspec, nk, (int)splane,
+                       n * splane, 0, 1.0f / ((float)g.Fy * (float)g.Fx));
+    if ((rc = fft_c2r(pm, spec, real, st))) return rc;
+    hipLaunchKernelGGL(k_plane_crop, dim3(grid_for((int64_t)n * H * W)), dim3(SC_BLOCK), 0, st, real, n, H, W, g.Fy, g.Fx, g.oy, g.ox, out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    (void)hipFree(real); (void)hipFree(kreal); (void)hipFree(spec); (void)hipFree(kspec);
+    return SCARLET_OK;
+}
+
 extern "C" int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *stream)
 {
     int rc = check_batch(b);
     if (rc) return rc;
+    if (b->diff_kernel) return backward_step_psf(b, approximate_L, stream);
     GradArgs a = grad_args(b, approximate_L);
     dim3 grid(a.T, a.S);
     hipStream_t st = (hipStream_t)stream;
@@ -641,7 +820,7 @@ static size_t fused_lds_bytes(const scarlet_batch *b)
 }
 static bool fused_ok(const scarlet_batch *b, int approximate_L)
 {
-    if (approximate_L || getenv("SCARLET_NO_FUSED")) return false;
+    if (approximate_L || b->diff_kernel || getenv("SCARLET_NO_FUSED")) return false;
     if (b->H > 64 || b->W > 64 || (b->W & 3) || b->H < 3 || b->W < 3) return false;
     return fused_lds_bytes(b) <= LDS_LIMIT - 4096;
 }
@@ -699,7 +878,7 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
     if (max_iter < 0) return set_err(SCARLET_E_ARG, "max_iter < 0");
     hipStream_t st = (hipStream_t)stream;
     int launched = 0;
-    int *d_count = (int *)((char *)b->workspace + scarlet_batch_workspace_bytes(b) - 64);
+    int *d_count = (int *)((char *)b->workspace + base_workspace_bytes(b) - 64);
     const bool fused = fused_ok(b, approximate_L);
     for (int i = 0; i < max_iter; ++i) {
         if (fused) {
@@ -737,6 +916,7 @@ struct InitArgs {
     double bg_rms[SC_BMAX];
     double sed_scale[SC_BMAX];
     int has_scale;
+    int do_symmetric, do_monotonic;
     double thresh;
 };
 
@@ -778,8 +958,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_init_extended(InitArgs a)
     }
     __syncthreads();
     const SymWindow sw = sym_window(H, W, cy, cx);
-    flip_symmetry_tile<double>(t, sw, true, 1.0);                 // sdss (source.py:162)
-    monotonic_tile<false, double>(t, cy, cx, 0.1);                // thresh=.1 (source.py:165-167)
+    if (a.do_symmetric) flip_symmetry_tile<double>(t, sw, true, 1.0);      // sdss (source.py:162)
+    if (a.do_monotonic) monotonic_tile<false, double>(t, cy, cx, 0.1);     // thresh=.1 (source.py:165-167)
     double cnt = 0;
     for (int i = threadIdx.x; i < HW; i += SC_BLOCK)
         if (t.m[(i / W) * t.LW + (i % W)] > cutoff) cnt += 1;
@@ -801,7 +981,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_init_extended(InitArgs a)
 }
 
 extern "C" int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host, float thresh,
-                                     const float *sed_scale_host, void *stream)
+                                     const float *sed_scale_host, int init_symmetric, int init_monotonic,
+                                     int run_update, void *stream)
 {
     int rc = check_batch(b);
     if (rc) return rc;
@@ -811,6 +992,7 @@ extern "C" int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host,
     a.images = b->images; a.sed[0] = b->sed[0]; a.sed[1] = b->sed[1];
     a.morph[0] = b->morph[0]; a.morph[1] = b->morph[1]; a.cur = b->cur; a.centers = b->centers; a.flags = b->flags;
     a.has_scale = sed_scale_host != nullptr; a.thresh = thresh;
+    a.do_symmetric = init_symmetric; a.do_monotonic = init_monotonic;
     for (int i = 0; i < SC_BMAX; ++i) {
         a.bg_rms[i] = i < b->B ? (double)bg_rms_host[i] : 1.0;
         a.sed_scale[i] = (i < b->B && sed_scale_host) ? (double)sed_scale_host[i] : 1.0;
@@ -822,5 +1004,39 @@ extern "C" int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host,
     if (rc) return rc;
     hipLaunchKernelGGL(k_init_extended, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
-    return launch_update(b, 0, 1, stream);                         // constructor's self.update()
+    return run_update ? launch_update(b, 0, 1, stream) : SCARLET_OK;   // constructor's self.update()
+}
+
+// ---- convergence sums for the Python-override path (the built-in pipeline computes them itself)
+__global__ __launch_bounds__(SC_BLOCK) void k_conv_sums(int K, int B, int HW, float *const sed0, float *const sed1,
+                                                        float *const morph0, float *const morph1, const int *cur,
+                                                        const int *active, double *conv)
+{
+    __shared__ double red[SC_NWAVES];
+    const int c = blockIdx.x, s = c / K;
+    if (!active[s]) return;
+    const int c0 = cur[s];
+    const float *mn = (c0 ? morph0 : morph1) + (size_t)c * HW, *ml = (c0 ? morph1 : morph0) + (size_t)c * HW;
+    const float *sn = (c0 ? sed0 : sed1) + (size_t)c * B, *sl = (c0 ? sed1 : sed0) + (size_t)c * B;
+    double d2 = 0, n2 = 0, d2s = 0, n2s = 0;
+    for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
+        const float v = mn[i], d = ml[i] - v;
+        d2 += (double)(d * d); n2 += (double)(v * v);
+    }
+    for (int i = threadIdx.x; i < B; i += SC_BLOCK) {
+        const float v = sn[i], d = sl[i] - v;
+        d2s += (double)(d * d); n2s += (double)(v * v);
+    }
+    d2 = block_sum(d2, red); n2 = block_sum(n2, red); d2s = block_sum(d2s, red); n2s = block_sum(n2s, red);
+    if (threadIdx.x == 0) { conv[4 * c] = d2s; conv[4 * c + 1] = n2s; conv[4 * c + 2] = d2; conv[4 * c + 3] = n2; }
+}
+
+extern "C" int scarlet_convergence_sums(scarlet_batch *b, void *stream)
+{
+    int rc = check_batch(b);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_conv_sums, dim3(b->S * b->K), dim3(SC_BLOCK), 0, (hipStream_t)stream, b->K, b->B,
+                       b->H * b->W, b->sed[0], b->sed[1], b->morph[0], b->morph[1], b->cur, b->active, ws_conv(b));
+    HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
 }

@@ -330,7 +330,11 @@ __device__ inline void wave_kspace_symmetry(const Tile &t, const SymWindow &s, d
 __device__ inline void wave_symmetry(const Tile &t, int cy, int cx, int algorithm, float strength,
                                      double dy, double dx, bool use_fill, float fill, float *vec)
 {
-    const SymWindow s = sym_window(t.H, t.W, cy, cx);
+    SymWindow s = sym_window(t.H, t.W, cy, cx);
+    if (algorithm & SCARLET_SYM_FULL_WINDOW) {   // bare operator on the whole array (operator.py:231-288)
+        algorithm &= ~SCARLET_SYM_FULL_WINDOW;
+        s.y0 = 0; s.x0 = 0; s.h = t.H; s.w = t.W; s.centered = false;
+    }
     if (algorithm == SCARLET_SYM_KSPACE) {
         if (s.centered) return;
         wave_kspace_symmetry(t, s, dy, dx, vec);

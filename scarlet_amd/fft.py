@@ -115,3 +115,34 @@ class Fourier(object):
 
     def __getitem__(self, index):
         return Fourier(self._image[index])
+
+
+# ---------------------------------------------------------------------------------------
+# Setup-time k-space helpers (host, numpy).  They run once per scene in Observation.match,
+# not in the iteration (SURVEY.md 8f rank 2 moves them to the device later); the
+# per-iteration convolution of the model (row a3b) is done by the HIP engine.
+def _kspace(image, fshape, axes):
+    """pad -> ifftshift -> rfftn (reference Fourier.fft, fft.py:193-211)."""
+    return np.fft.rfftn(np.fft.ifftshift(_pad(image, fshape, axes), axes), axes=axes)
+
+
+def _from_kspace(spec, fshape, image_shape, axes):
+    """irfftn -> fftshift -> central crop (reference Fourier.from_fft, fft.py:138-181)."""
+    return _centered(np.fft.fftshift(np.fft.irfftn(spec, fshape, axes=axes), axes=axes), image_shape)
+
+
+def match_psfs(psf1, psf2, padding=3, axes=(-2, -1)):
+    """Difference kernel that turns `psf2` into `psf1`: ratio of the spectra, cropped to the
+    larger image shape (reference fft.match_psfs, fft.py:282-301).  Fourier in, Fourier out."""
+    shape = psf2.shape if psf1.shape[0] < psf2.shape[0] else psf1.shape
+    F = _get_fft_shape(psf1.image, psf2.image, padding, axes)
+    spec = _kspace(psf1.image, F, axes) / _kspace(psf2.image, F, axes)
+    return Fourier(_from_kspace(spec, F, shape, axes))
+
+
+def convolve(image1, image2, padding=3, axes=(-2, -1)):
+    """Linear convolution of two `Fourier` images cropped to image1's shape
+    (reference fft.convolve, fft.py:304-317).  Host helper for setup and tests."""
+    F = _get_fft_shape(image1.image, image2.image, padding, axes)
+    spec = _kspace(image1.image, F, axes) * _kspace(image2.image, F, axes)
+    return Fourier(_from_kspace(spec, F, image1.shape, axes))

@@ -1,0 +1,281 @@
+"""-m gpu: the scarlet-style Python API (Frame / Observation / Component / Blend / update.* /
+operator.*) on top of the HIP library.  These tests read like the reference's own tests
+(tests/test_component.py, test_update.py, test_operator.py, test_source.py, test_blend.py);
+the golden arrays are the reference's."""
+import numpy as np
+import pytest
+from numpy.testing import assert_almost_equal, assert_array_equal
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def scarlet():
+    import scarlet_amd
+    scarlet_amd._lib.require_gpu()
+    return scarlet_amd
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+# ------------------------------------------------------------------ tests/test_component.py
+def test_component_methods(scarlet):
+    sed = np.arange(5); morph = np.arange(20).reshape(4, 5)
+    frame = scarlet.Frame((5, 4, 5))
+    c = scarlet.Component(frame, sed, morph)
+    truth = sed[:, None, None] * morph[None]
+    assert_array_equal(npy(c.get_model()), truth)
+    other = c.get_model(torch.ones(5, device="cuda"), c.morph + 10)
+    assert_array_equal(npy(other), np.ones(5)[:, None, None] * (morph + 10)[None])
+    assert_array_equal(npy(c.get_flux()), truth.sum(axis=(1, 2)))
+    assert c.update() is c and c.coord is None and c.step_sed == 1 and c.step_morph == 1
+    with pytest.raises(ValueError):
+        c.get_model(sed=c.sed)
+
+
+def test_component_tree(scarlet):
+    class UpdateComponent(scarlet.Component):
+        def __init__(self, norm="sed", *args, **kwargs):
+            self.norm = norm
+            super().__init__(*args, **kwargs)
+
+        def update(self):
+            scarlet.update.normalized(self, self.norm)
+
+    frame = scarlet.Frame((3, 5, 5))
+    sed = np.arange(3, dtype=np.float32); morph = np.arange(25, dtype=np.float32).reshape(5, 5)
+    c1, c2, c3, c4 = [UpdateComponent(frame=frame, sed=sed, morph=morph) for _ in range(4)]
+    c5 = UpdateComponent("morph", frame, sed, morph)
+    tree1 = scarlet.ComponentTree([c1, c2]); tree2 = scarlet.ComponentTree([c3, c4])
+    assert c1.coord == (0,) and c2._parent is tree1 and tree1.K == 2
+    tree1 += tree2
+    assert tree1.components == (c1, c2, c3, c4) and tree1.n_sources == 4
+    tree1 += c5
+    assert tree1.components == (c1, c2, c3, c4, c5) and tree2.components == (c3, c4)
+    tree2.update()
+    assert_array_equal(npy(c1.sed), sed); assert_array_equal(npy(c3.sed), sed / sed.sum())
+    assert_array_equal(npy(c3.morph), morph * sed.sum())
+    tree1.update()
+    assert_array_equal(npy(c1.sed), sed / sed.sum()); assert_array_equal(npy(c5.sed), sed * morph.sum())
+    assert_array_equal(npy(c5.morph), morph / morph.sum())
+    t = scarlet.ComponentTree([scarlet.ComponentTree([c1]), c2])
+    assert_array_equal(npy(t.get_model()), npy(c1.get_model() + c2.get_model()))
+    with pytest.raises(NotImplementedError):
+        scarlet.ComponentTree([1, 2])
+
+
+# ------------------------------------------------------------------ tests/test_update.py
+def test_update_functions(scarlet):
+    update = scarlet.update
+    frame = scarlet.Frame((6, 3, 3))
+    sed = np.array([-.1, .1, 4, -.2, .2, 0], dtype=np.float32)
+    morph = np.array([[-1, -.5, -1], [.1, 2, .3], [-.5, .3, 0]], dtype=np.float32)
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); update.positive_sed(src)
+    assert_array_equal(npy(src.sed), np.array([0, .1, 4, 0, .2, 0], np.float32)); assert_array_equal(npy(src.morph), morph)
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); update.positive(src)
+    assert_array_equal(npy(src.morph), np.array([[0, 0, 0], [.1, 2, .3], [0, .3, 0]], np.float32))
+    frame = scarlet.Frame((6, 5, 5))
+    sed = np.arange(6, dtype=np.float32); morph = np.arange(25, dtype=np.float32).reshape(5, 5)
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); update.normalized(src, type='sed')
+    assert_array_equal(npy(src.sed), sed / 15); assert_array_equal(npy(src.morph), morph * 15)
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); update.normalized(src)
+    assert_array_equal(npy(src.sed), sed * 24); assert_array_equal(npy(src.morph), morph / 24)
+    with pytest.raises(ValueError):
+        update.normalized(src, type='fubar')
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); src.L_morph = 1
+    update.sparse_l0(src, thresh=4)
+    t = morph.copy(); t[0, :-1] = 0
+    assert_array_equal(npy(src.morph), t)
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); src.L_morph = 0.5
+    update.sparse_l1(src, thresh=2)
+    t = np.zeros(25, np.float32); t[5:] = np.arange(20) + 1
+    assert_array_equal(npy(src.morph), t.reshape(5, 5))
+
+
+def test_update_monotonic_symmetric(scarlet):
+    update = scarlet.update
+    frame = scarlet.Frame((6, 5, 5))
+    sed = np.arange(6); morph = np.arange(25, dtype=float).reshape(5, 5)
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); src.L_morph = 1
+    update.monotonic(src, (2, 2), use_nearest=True, exact=False, thresh=0)
+    assert_array_equal(npy(src.morph), [[0, 1, 2, 3, 4], [5, 6, 7, 8, 9], [10, 11, 12, 12, 12],
+                                        [11, 12, 12, 12, 12], [12, 12, 12, 12, 12]])
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); src.L_morph = 1
+    update.monotonic(src, (2, 2))
+    new_X = [[0.000000000, 1.000000000, 2.000000000, 3.000000000, 4.000000000],
+             [5.000000000, 6.000000000, 7.000000000, 8.000000000, 9.000000000],
+             [9.742640687, 11.000000000, 12.000000000, 12.000000000, 10.828427125],
+             [11.030627697, 11.707106781, 12.000000000, 12.000000000, 11.771236166],
+             [11.556349186, 11.868867239, 11.914213562, 11.983249156, 11.928090416]]
+    assert_almost_equal(npy(src.morph), new_X, decimal=5)
+    with pytest.raises(ValueError):
+        update.monotonic(src, (2, 2), use_nearest=True, thresh=.25)
+    with pytest.raises(NotImplementedError):
+        update.monotonic(src, (2, 2), exact=True)
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); src.L_morph = 1
+    update.monotonic(src, (2, 2), thresh=.25)
+    assert_almost_equal(npy(src.morph)[1, 3:], [7.242640687, 5.806841831], decimal=5)
+    # symmetry (reference tests/test_update.py:178-211)
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); src.L_morph = 1; src.pixel_center = (2, 2)
+    update.symmetric(src, src.pixel_center)
+    assert_array_equal(npy(src.morph), np.ones_like(morph) * 12)
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); src.L_morph = 1
+    update.symmetric(src, (2, 2), strength=.5, algorithm="soft")
+    assert_array_equal(npy(src.morph), np.arange(6, 18.5, .5).reshape(5, 5))
+    src = scarlet.Component(frame, sed.copy(), morph.copy()); src.L_morph = 1
+    update.symmetric(src, (1, 1))
+    t = morph.copy(); t[:3, :3] = 6
+    assert_array_equal(npy(src.morph), t)
+    # bbox arguments: fixtures from the reference (incl. its all-zero symmetric quirk)
+    g = load_golden("update")
+    frame = scarlet.Frame((5, 24, 28))
+    bbox = scarlet.Box.from_bounds(*[int(v) for v in g["bbox"]])
+    c = scarlet.Component(frame, g["sed"], g["morph"]); c.L_morph = 2.
+    update.monotonic(c, (11, 14), bbox=bbox)
+    assert rel_err(npy(c.morph), g["mono_bbox"]) < 1e-5
+    c = scarlet.Component(frame, g["sed"], g["morph"]); c.L_morph = 2.; c.shift = np.array((0.2, -0.1))
+    update.symmetric(c, (11, 14), bbox=bbox)
+    assert_array_equal(npy(c.morph), g["sym_bbox"])
+
+
+# ------------------------------------------------------------------ tests/test_operator.py
+def test_operator_functions(scarlet):
+    op = scarlet.operator
+    X = np.arange(25).reshape(5, 5).astype(np.float64)
+    prox = op.prox_strict_monotonic(X.shape, use_nearest=True, thresh=0)
+    _X = X.copy(); prox(_X, 0.0)
+    assert_array_equal(_X[2:], [[10, 11, 12, 12, 12], [11, 12, 12, 12, 12], [12, 12, 12, 12, 12]])
+    with pytest.raises(ValueError):
+        op.prox_strict_monotonic(X.shape, use_nearest=True, thresh=.25)
+    prox = op.prox_strict_monotonic(X.shape, use_nearest=False, thresh=0)
+    _X = X.copy(); prox(_X, 0.0)
+    assert_almost_equal(_X[2, 0], 9.74264069, decimal=5); assert_almost_equal(_X[4, 4], 11.92809042, decimal=5)
+    Z = np.zeros((5, 5)); op.prox_center_on(Z, 0); assert Z[2, 2] == 1e-10
+    Z = np.zeros((5, 5)); op.prox_sed_on(Z, 0, .1); assert_array_equal(Z, np.ones((5, 5)) * .1)
+    M = np.arange(11, dtype=np.float32).reshape(1, 11); op.prox_max_unity(M, 0)
+    assert_array_equal(M, (np.arange(11, dtype=np.float32) / 10).reshape(1, 11))
+    _X = X.copy(); op.prox_soft_symmetry(_X, 0); assert_array_equal(_X, np.ones_like(X) * 12)
+    _X = X.copy(); op.prox_soft_symmetry(_X, 0, 0); assert_array_equal(_X, X)
+    _X = X.copy(); op.prox_soft_symmetry(_X, 0, .5); assert_array_equal(_X, np.arange(6, 18.5, .5).reshape(5, 5))
+    x = np.zeros((21, 21))
+    x[8:13, 8:13] = [[1, 2, 3, 2, 1], [2, 3, 4, 3, 1], [3, 4, 5, 1, 1], [2, 3, 1, 1, 1], [1, 1, 1, 1, 1]]
+    assert_almost_equal(op.prox_kspace_symmetry(x, None, (0, 0)), (x[::-1, ::-1] + x) / 2, decimal=5)
+    g = load_golden("symmetry")
+    assert rel_err(op.prox_kspace_symmetry(g["kx"], 0, shift=(0.3, -0.45)), g["ky"]) < 1e-5
+    assert rel_err(op.prox_kspace_symmetry(g["kx2"], 0, shift=(-0.2, 0.15)), g["ky2"]) < 1e-5
+    with pytest.raises(ValueError):
+        op.prox_uncentered_symmetry(X.copy(), 0, (2, 2), algorithm="fubar")
+
+
+def test_uncentered_operator(scarlet):
+    op = scarlet.operator
+
+    def prox_plus(X, step):
+        X[X < 0] = 0
+        return X
+    for flip in (False, True):
+        x = np.arange(35).reshape(5, 7)
+        x = (x[::-1] if flip else x) - 5
+        x = x.astype(np.float32)
+        shape = x.shape
+        for c, region in [((2, 3), (slice(None), slice(None))), ((1, 2), (slice(0, 3), slice(0, 5))),
+                          ((1, shape[1] - 3), (slice(0, 3), slice(-5, shape[1]))),
+                          ((shape[0] - 2, 2), (slice(-3, shape[0]), slice(0, 5))),
+                          ((shape[0] - 2, shape[1] - 3), (slice(-3, shape[0]), slice(-5, shape[1])))]:
+            truth = x.copy(); truth[region][x[region] < 0] = 0
+            _x = x.copy(); op.uncentered_operator(_x, prox_plus, c, step=1)
+            assert_array_equal(_x, truth)
+            truthf = np.zeros_like(x); truthf[region][x[region] > 0] = x[region][x[region] > 0]
+            _x = x.copy(); op.uncentered_operator(_x, prox_plus, c, step=1, fill=0)
+            assert_array_equal(_x, truthf)
+
+
+def test_measurement(scarlet):
+    morph = np.zeros((15, 15)); morph[4, 7] = 1; morph[11, 9] = 2
+    assert scarlet.measurement.max_pixel(morph, (5, 5)) == (4, 7)
+    assert scarlet.measurement.max_pixel(morph, (5, 5), window=(slice(0, 15),) * 2) == (11, 9)
+    g = load_golden("measure")
+    nc, sh = scarlet.measurement.psf_weighted_centroid(g["m0"].astype(np.float32), g["psf"], tuple(g["maxpix0"]))
+    assert nc == tuple(g["cen32_0"]); assert_almost_equal(sh, g["shift32_0"], decimal=6)
+
+
+# ------------------------------------------------------------------ tests/test_source.py
+def test_sources(scarlet):
+    shape = (5, 11, 15)
+    x, y = np.meshgrid(np.linspace(-2, 2, 5), np.linspace(-2, 2, 5))
+    r = np.sqrt(x ** 2 + y ** 2)
+    true_sed = np.arange(5); true_morph = np.zeros(shape[1:])
+    skycoord = (np.array(true_morph.shape) - 1) // 2
+    cy, cx = skycoord
+    true_morph[cy - 2:cy + 3, cx - 2:cx + 3] = 3 - r
+    morph = true_morph.copy(); morph[5, 3] = 10
+    images = (true_sed[:, None, None] * morph[None]).astype(np.float32)
+    frame = scarlet.Frame(shape)
+    obs = scarlet.Observation(images).match(frame)
+    bg_rms = np.ones(5) * 1e-3
+    sed, m = scarlet.init_extended_source(skycoord, frame, obs, bg_rms)
+    assert_array_equal(npy(sed) / 3, true_sed); assert_almost_equal(npy(m) * 3, true_morph, decimal=5)
+    src = scarlet.ExtendedSource(frame, skycoord, obs, bg_rms)
+    assert_array_equal(src.pixel_center, skycoord)
+    assert src.symmetric is True and src.monotonic is True and src.center_step == 5 and src.delay_thresh == 10
+    assert_almost_equal(npy(src.morph) * 3, true_morph, decimal=5)
+    morph = true_morph.copy(); morph[5, 5] = 2
+    obs = scarlet.Observation((true_sed[:, None, None] * morph[None]).astype(np.float32)).match(frame)
+    sed, m = scarlet.init_extended_source(skycoord, frame, obs, bg_rms, symmetric=False)
+    t = true_morph.copy(); t[5, 5] = 1.5816233815926433
+    assert_almost_equal(npy(m) * 3, t, decimal=5)
+    sed, m = scarlet.init_extended_source(skycoord, frame, obs, bg_rms, monotonic=False)
+    assert_almost_equal(npy(m) * 3, true_morph, decimal=5)
+    with pytest.raises(scarlet.SourceInitError):
+        scarlet.init_extended_source(skycoord, frame, obs, np.ones(5) * 1e3)
+    # PointSource without PSF (reference tests/test_source.py:47-66)
+    ps = scarlet.PointSource(frame, (4, 8), obs)
+    t = np.zeros(shape[1:]); t[4, 8] = 1
+    assert_array_equal(npy(ps.morph), t); assert ps.pixel_center == (4, 8)
+    assert_array_equal(scarlet.get_pixel_sed((3, 2), obs), obs.images[:, 3, 2])
+
+
+# ------------------------------------------------------------------ tests/test_blend.py (no-PSF part)
+def test_blend_fit_matches_reference_and_both_pipelines_agree(scarlet):
+    from scarlet_amd import synth
+    g = load_golden("fit_synth")
+    scn = synth.make_scene(0)
+    frame = scarlet.Frame(scn["images"].shape)
+    obs = scarlet.Observation(scn["images"]).match(frame)
+    bg = np.ones(5) * 0.1
+    srcs = [scarlet.ExtendedSource(frame, tuple(int(v) for v in p), obs, bg) for p in scn["centers"]]
+    assert rel_err(np.array([npy(s.morph) for s in srcs]), g["s0_f32_init_morph"]) < 1e-5
+    assert_array_equal(np.array([s.pixel_center for s in srcs]), g["s0_f32_init_center"])
+    blend = scarlet.Blend(srcs, obs)
+    blend.fit(30, e_rel=0)
+    assert blend.it == 30 and len(blend.mse) == 30
+    assert rel_err(blend.mse, g["s0_f32_mse"]) < 1e-5
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["s0_f32_morph"]) < 1e-5
+    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["s0_f32_sed"]) < 1e-5
+    assert_array_equal(np.array([c.pixel_center for c in blend.components]), g["s0_f32_center"])
+    mse = np.array(blend.mse)
+    # re-entrant fit (reference docs/user_docs cell 46): 10 more iterations continue the run
+    blend.fit(10, e_rel=0)
+    assert blend.it == 40
+
+    # the same fit through the Python pipeline: a subclass that overrides update()
+    class MySource(scarlet.ExtendedSource):
+        def update(self):
+            return super().update()
+    srcs2 = [MySource(frame, tuple(int(v) for v in p), obs, bg) for p in scn["centers"]]
+    blend2 = scarlet.Blend(srcs2, obs)
+    assert not blend2._builtin_pipeline()
+    blend2.fit(30, e_rel=0)
+    assert blend2.it == 30
+    assert rel_err(blend2.mse, mse) < 1e-5
+    assert rel_err(np.array([npy(c.morph) for c in blend2.components]), g["s0_f32_morph"]) < 1e-5
+    assert_array_equal(np.array([c.pixel_center for c in blend2.components]), g["s0_f32_center"])
+    # ragged stop: e_rel=1e-2 converges at the reference's iteration count
+    srcs3 = [scarlet.ExtendedSource(frame, tuple(int(v) for v in p), obs, bg) for p in scn["centers"]]
+    blend3 = scarlet.Blend(srcs3, obs).fit(200, e_rel=1e-2)
+    assert blend3.it == int(g["s0_f32_erel_it"]) and blend3.converged

@@ -1,0 +1,156 @@
+"""-m gpu: the PSF (FFT-convolution) path, row a3b: render, its adjoint inside the fit, and
+BASELINE config 1 (hsc_cosmos_35, 5x58x48, PSF 43x43, K=2, 50 iterations)."""
+import numpy as np
+import pytest
+from numpy.testing import assert_almost_equal, assert_array_equal
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def scarlet():
+    import scarlet_amd
+    scarlet_amd._lib.require_gpu()
+    return scarlet_amd
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+def test_convolve_same_matches_reference(scarlet):
+    from scarlet_amd.psfconv import convolve_same
+    g = load_golden("fft")
+    out = npy(convolve_same(g["img"], g["ker"]))
+    assert rel_err(out, g["conv"]) < 1e-5
+    # narrow -> wide PSF round trip (reference tests/test_fft.py:73-90)
+    out = npy(convolve_same(g["psf1"][None], g["k12"][None]))[0]
+    assert_almost_equal(out, g["psf2"], decimal=6)
+    # odd/even shape mix against the oracle
+    from oracle import pgm
+    rng = np.random.RandomState(0)
+    for shape, ks in (((2, 31, 55), (2, 41, 41)), ((3, 58, 48), (1, 43, 43)), ((1, 64, 64), (1, 8, 3)), ((2, 33, 20), (2, 6, 9))):
+        img = rng.rand(*shape); ker = rng.rand(*ks)
+        ref = pgm.convolve(img, np.broadcast_to(ker, (shape[0],) + ks[1:]), axes=(1, 2))
+        assert rel_err(npy(convolve_same(img, ker)), ref) < 1e-5, (shape, ks)
+
+
+def test_gradient_step_with_psf_matches_oracle(scarlet):
+    """one backward+step with a difference kernel and per-pixel weights vs the CPU oracle"""
+    from oracle import pgm
+    g = load_golden("grad")
+    images = g["images"].astype(np.float32); weights = g["weights"].astype(np.float32)
+    B, H, W = images.shape
+    K = 2
+    diff = g["diff_psf"].astype(np.float32)
+    b = scarlet.BlendBatch(images[None], np.array([[[10, 12], [5, 6]]], dtype=np.int32), weights=weights[None],
+                           symmetric=False, monotonic=False)
+    b.set_diff_kernel(diff)
+    b.set_state(g["seds"][None], g["morphs"][None])
+    import ctypes
+    from scarlet_amd import _lib
+    _lib.check(_lib.lib.scarlet_backward_step(ctypes.byref(b._c), 0, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    seds = [s.astype(np.float32) for s in g["seds"]]; morphs = [m.astype(np.float32) for m in g["morphs"]]
+    loss, gs, gm = pgm.loss_and_gradients(seds, morphs, images, weights, diff)
+    L_sed, L_morph = pgm.lipschitz(seds, morphs)
+    assert rel_err(b.lipschitz[0].cpu().numpy(), [L_sed, L_morph]) < 1e-5
+    assert abs(float(b.mse_buf[0, 0].item()) - loss) < 1e-5 * abs(loss)
+    want_sed = np.array(seds) - np.array(gs) / L_sed
+    want_morph = np.array(morphs) - np.array(gm) / L_morph
+    assert rel_err(b.sed[1][0].cpu().numpy(), want_sed) < 1e-5
+    assert rel_err(b.morph[1][0].cpu().numpy(), want_morph) < 1e-5
+
+
+@pytest.mark.parametrize("tag,tol", [("f32", 2e-5), ("f64", 2e-5)])
+def test_config1_hsc_fifty_iterations(scarlet, tag, tol):
+    """BASELINE config 1 through the batched engine, from the reference's initial state."""
+    g = load_golden("fit_hsc")
+    d = load_golden("hsc_inputs")
+    b = scarlet.BlendBatch(d["images"][None], g["init_center_" + tag][None].astype(np.int32),
+                           centroid_weight=g["model_psf"][0])
+    b.set_diff_kernel(g["diff_kernel"].astype(np.float32))
+    b.set_state(g["init_sed_" + tag][None], g["init_morph_" + tag][None], shifts=g["init_shift_" + tag][None])
+    b.fit(50, e_rel=0)
+    torch.cuda.synchronize()
+    assert_array_equal(b.centers[0].cpu().numpy(), g["center_" + tag])
+    assert rel_err(b.mse(0), g["mse_" + tag]) < tol
+    assert rel_err(b.sed_current[0].cpu().numpy(), g["sed_" + tag]) < tol
+    assert rel_err(b.morph_current[0].cpu().numpy(), g["morph_" + tag]) < tol
+    assert int(b.status.abs().sum().item()) == 0
+
+
+def test_config1_through_the_scarlet_api(scarlet):
+    """docs/quickstart.ipynb cells 3-14 with our imports: Frame / Observation.match /
+    ExtendedSource / Blend.fit on the hsc_cosmos_35 data."""
+    g = load_golden("fit_hsc")
+    d = load_golden("hsc_inputs")
+    images = d["images"]
+    psfs = g["obs_psfs"].astype(np.float32)
+    frame = scarlet.Frame(images.shape, psfs=g["model_psf"].astype(np.float32))
+    obs = scarlet.Observation(images, psfs=psfs).match(frame)
+    assert rel_err(obs._diff_kernels.image, g["diff_kernel"]) < 1e-5
+    bg = np.ones(5) * 0.1
+    srcs = [scarlet.ExtendedSource(frame, tuple(int(v) for v in p), obs, bg) for p in g["pixels"]]
+    assert rel_err(np.array([npy(s.morph) for s in srcs]), g["init_morph_f32"]) < 2e-5
+    assert rel_err(np.array([npy(s.sed) for s in srcs]), g["init_sed_f32"]) < 2e-5
+    blend = scarlet.Blend(srcs, obs).fit(50, e_rel=0)
+    assert blend.it == 50
+    assert rel_err(blend.mse, g["mse_f32"]) < 1e-4
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["morph_f32"]) < 1e-4
+    assert_array_equal(np.array([c.pixel_center for c in blend.components]), g["center_f32"])
+    model = obs.render(blend.get_model())
+    assert model.shape == images.shape
+
+
+def init_data(scarlet, shape, coords, amplitudes, dtype=np.float32):
+    """reference tests/test_blend.py:7-53 (data only)"""
+    import scipy.signal
+    B, Ny, Nx = shape
+    K = len(coords)
+    _seds = [np.arange(B, dtype=dtype), np.arange(B, dtype=dtype)[::-1], np.ones((B,), dtype=dtype)]
+    seds = np.array([_seds[n % 3] * amplitudes[n] for n in range(K)])
+    morphs = np.zeros((K, Ny, Nx))
+    for k, coord in enumerate(coords):
+        morphs[k, coord[0], coord[1]] = 1
+    images = seds.T.dot(morphs.reshape(K, -1)).reshape(shape)
+    psf_shape = (41, 41)
+    target_psf = scarlet.psf.generate_psf_image(scarlet.psf.gaussian, psf_shape, sigma=.9).image
+    target_psf /= target_psf.sum()
+    psfs = np.array([scarlet.psf.generate_psf_image(scarlet.psf.gaussian, psf_shape, sigma=1 + .2 * b).image
+                     for b in range(B)], dtype=dtype)
+    psfs /= psfs.max(axis=(1, 2))[:, None, None]
+    images = np.array([scipy.signal.convolve(img, psf, method="direct", mode="same")
+                       for img, psf in zip(images, psfs)], dtype=dtype)
+    psfs /= psfs.sum(axis=(1, 2))[:, None, None]
+    return target_psf, psfs, images, seds
+
+
+def test_reference_blend_tests(scarlet):
+    """reference tests/test_blend.py:56-122 (float32 engine: tolerances adapted)"""
+    shape = (6, 31, 55)
+    coords = [(20, 10), (10, 30), (17, 42)]
+    target_psf, psfs, images, seds = init_data(scarlet, shape, coords, [3, 2, 1])
+    frame = scarlet.Frame(images.shape, psfs=target_psf[None].astype(np.float32))
+    obs = scarlet.Observation(images, psfs=psfs).match(frame)
+    sources = [scarlet.PointSource(frame, coord, obs) for coord in coords]
+    blend = scarlet.Blend(sources, obs)
+    model = npy(obs.render(blend.get_model()))
+    assert_almost_equal(images, model, decimal=4)
+    blend.fit(10)
+    assert blend.it == 2
+    assert max(blend.mse) < 1e-8
+    # ExtendedSource (tests/test_blend.py:96-122)
+    bg_rms = np.ones((6,))
+    sources = [scarlet.ExtendedSource(frame, coord, obs, bg_rms) for coord in coords]
+    blend = scarlet.Blend(sources, obs)
+    psf_scale = obs.frame.psfs.max(axis=(1, 2)) / frame.psfs[0].max()
+    scaled_seds = np.array([npy(c.sed) * psf_scale for c in blend.components])
+    assert_almost_equal(scaled_seds, seds, decimal=4)
+    blend.fit(100)
+    assert blend.it < 20
+    mse = np.array(blend.mse)
+    assert np.all(mse[:-1] - mse[1:] >= -1e-9)

@@ -1,0 +1,107 @@
+"""CPU: host-side logic of the product (no device work): boxes, cache, pad/centre layouts,
+PSF profiles, scene sharding arithmetic, synthetic generator determinism.  The expected
+arrays are the golden vectors of the reference's own tests (cited per test)."""
+import numpy as np
+import pytest
+from numpy.testing import assert_array_equal, assert_almost_equal
+
+import scarlet_amd as sc
+from scarlet_amd import fft, psf, synth, distributed
+
+
+def test_box_reference_vectors():
+    # reference tests/test_bbox.py
+    b1 = sc.Box((4, 1), 7, 6)
+    assert (b1.bottom, b1.top, b1.left, b1.right) == (4, 10, 1, 6)
+    assert b1.slices == (slice(4, 11), slice(1, 7)) and b1.shape == (7, 6) and not b1.is_empty
+    b2 = sc.Box.from_bounds(4, 10, 1, 6)
+    assert b2 == b1 and b2.slices == b1.slices
+    e = sc.Box.from_bounds(10, 9, 5, 10)
+    assert e.is_empty and e.width == 0 and e.bottom is None and e.yx0 is None
+    a = sc.Box((5, 10), 9, 7)
+    c = a.copy()
+    assert c == a and c is not a
+    o = sc.Box((10, 12), 10, 10)
+    u = a | o
+    assert (u.bottom, u.top, u.left, u.right) == (5, 19, 10, 21)
+    i = a & o
+    assert (i.bottom, i.top, i.left, i.right) == (10, 13, 12, 16)
+    assert (a & sc.Box((30, 30), 2, 2)).is_empty
+    assert str(a) == "((5, 13), (10, 16))"
+
+
+def test_trim_and_flux_at_edge():
+    X = np.zeros((11, 13))
+    X[3:7, 4:9] = 1
+    t = sc.trim(X)
+    assert (t.bottom, t.top, t.left, t.right) == (3, 6, 4, 8)
+    assert not sc.flux_at_edge(X)
+    X[0, 5] = 2
+    assert sc.flux_at_edge(X) and not sc.flux_at_edge(X, min_value=3)
+
+
+def test_cache_semantics():
+    sc.Cache._cache = {}
+    with pytest.raises(KeyError):
+        sc.Cache.check("a", 1)
+    sc.Cache.set("a", 1, "x")
+    assert sc.Cache.check("a", 1) == "x"
+
+
+def test_pad_center_layouts():
+    # reference tests/test_fft.py:9-68
+    a = fft._pad(np.ones((1, 1)), (5, 4))
+    truth = np.zeros((5, 4)); truth[2, 2] = 1
+    assert_array_equal(a, truth)
+    a0 = np.arange(10).reshape(5, 2)
+    ap = fft._pad(a0, (9, 11))
+    truth = np.zeros((9, 11), dtype=int); truth[2:7, 5:7] = a0
+    assert_array_equal(ap, truth)
+    assert_array_equal(np.fft.fftshift(np.fft.ifftshift(ap)), ap)
+    assert_array_equal(fft._centered(ap, (5, 2)), a0)
+    with pytest.raises(ValueError):
+        fft._centered(a0, (6, 2))
+    assert fft._get_fft_shape(np.zeros((5, 58, 48)), np.zeros((5, 43, 43)), 3, (1, 2)) == [108, 96]
+    assert fft._get_fft_shape(np.zeros((61, 61)), np.zeros((61, 61)), 10) == [135, 144]
+
+
+def test_psf_matching_round_trip():
+    # reference tests/test_fft.py:73-90
+    p1 = psf.generate_psf_image(psf.gaussian, (41, 41), sigma=1)
+    p2 = psf.generate_psf_image(psf.gaussian, (41, 41), sigma=2)
+    k12 = fft.match_psfs(p2, p1)
+    assert_almost_equal(fft.convolve(p1, k12).image, p2.image)
+
+
+def test_psf_reference_vectors():
+    # reference tests/test_psf.py
+    y = np.arange(7); x = np.arange(7)
+    g = psf.gaussian(y, x, 3, 5, 4.6, 1.872)
+    assert_almost_equal(g[3, 5], 4.6); assert_almost_equal(g[0, 0], 0.035972150170478605)
+    m = psf.moffat(y, x, 3, 5, 4.6, 1.123, 1.491)
+    assert_almost_equal(m[0, 0], 0.03206059739715075)
+    d = psf.double_gaussian(y, x, 3, 5, 4.2, .938, 2.042, 3.67)
+    assert_almost_equal(d[3, 5], 6.242)
+    img = psf.generate_psf_image(psf.gaussian, (5, 5), normalize=False, amplitude=1, sigma=.5).image
+    assert_almost_equal(img[2, 2], 1.1658125164); assert_almost_equal(img[0, 0], 0.0000048820)
+
+
+def test_shard_ranges_cover_everything():
+    for n in (0, 1, 7, 10000, 10001):
+        for w in (1, 2, 3, 8):
+            spans = [distributed.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_scenes_are_deterministic():
+    a, b = synth.make_scene(3), synth.make_scene(3)
+    assert_array_equal(a["images"], b["images"]); assert_array_equal(a["centers"], b["centers"])
+    assert a["images"].shape == (5, 64, 64) and a["images"].dtype == np.float32
+    c = a["centers"]
+    assert c.min() >= 8 and c.max() <= 55
+    for i in range(4):
+        for j in range(i):
+            assert max(abs(c[i] - c[j])) >= 4
