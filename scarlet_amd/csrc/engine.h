@@ -516,7 +516,8 @@ __device__ inline void wave_pipeline(const UpdateArgs &a, int c, float *lds_wave
         const bool none = (dy != dy);
         wave_symmetry(t, cy, cx, none ? SCARLET_SYM_SOFT : SCARLET_SYM_KSPACE, 1.0f, dy, dx, false, 0.f, vec);
     }
-    if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f);
+    int lstop = 1 << 30;                // last sweep level computed; pixels beyond are <= 0 -> 0
+    if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f, &lstop);
     if (lane == 0) { a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
     const float step_morph = 1.0f / (float)a.lipschitz[2 * s + 1];
     float vmax = -INFINITY;
@@ -529,7 +530,7 @@ __device__ inline void wave_pipeline(const UpdateArgs &a, int c, float *lds_wave
             const float mag = fabsf(v) - a.l1_thresh * step_morph;
             v = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
         }
-        if (v < 0.f) v = 0.f;
+        if (v < 0.f || sweep_level(i / W, i % W, cy, cx) > lstop) v = 0.f;
         *p = v;
         anynan |= (v != v);
         vmax = fmaxf(vmax, v);

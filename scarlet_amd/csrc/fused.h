@@ -144,7 +144,6 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
     constexpr int NG = KM * (KM + 1) / 2;
     constexpr int NP = 1 + KM * BM;
     constexpr int GPT = 4;                       // float4 groups per thread (H, W <= 64)
-    constexpr int GPW = 16;                      // float4 groups per lane in the per-wave passes
     constexpr bool PREFETCH = (KM <= 4);         // image prefetch needs 16*BM/4 more VGPRs
     __shared__ double red[SC_NWAVES][NP > NG ? NP : NG];
     __shared__ double tot[NP > NG ? NP : NG];
@@ -379,61 +378,54 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
             wave_symmetry(t, cy, cx, none ? SCARLET_SYM_SOFT : SCARLET_SYM_KSPACE, 1.0f, dy, dx, false, 0.f, vec);
         }
         STAMP(9);
-        if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f);
+        int lstop = 1 << 30;            // last sweep level computed; pixels beyond are <= 0 -> 0
+        if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f, &lstop);
         STAMP(10);
         if (lane == 0) { a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
-        // the previous iteration's morphology (L2-resident): issue the loads now
-        const float4 *last4 = reinterpret_cast<const float4 *>(min_g + (size_t)k * HW);
-        float4 lastv[GPW];
-#pragma unroll
-        for (int j = 0; j < GPW; ++j) {
-            const int g = lane + j * SC_WAVE;
-            lastv[j] = g < ngroups ? last4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        // sparsity, positivity, max in registers (update.py:71-82, 27-32, 62-65)
-        float4 vreg[GPW];
+        // sparsity, positivity, max (update.py:71-82, 27-32, 62-65): one pass over the LDS tile.
+        // (Two short passes through LDS instead of 128 live registers: the register version
+        // spilled and ran 2.5x slower.)
         float vmax = -INFINITY;
         bool anynan = false;
+#pragma unroll 4
+        for (int g = lane; g < ngroups; g += SC_WAVE) {
+            const int y = g / gpr, x = (g - y * gpr) << 2;
+            float *p = t.m + y * LW + x;
+            const float4 v4 = lds_load4(p);
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-        for (int j = 0; j < GPW; ++j) {
-            const int g = lane + j * SC_WAVE;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (g < ngroups) {
-                const int y = g / gpr, x = (g - y * gpr) << 2;
-                const float4 v4 = lds_load4(t.m + y * LW + x);
-                v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (a.l0_thresh >= 0.f && fabsf(v[e]) < a.l0_thresh * step_morph) v[e] = 0.f;
-                    if (a.l1_thresh >= 0.f) {
-                        const float mag = fabsf(v[e]) - a.l1_thresh * step_morph;
-                        v[e] = (v[e] > 0.f ? 1.f : (v[e] < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
-                    }
-                    if (v[e] < 0.f) v[e] = 0.f;
-                    anynan |= (v[e] != v[e]);
-                    vmax = fmaxf(vmax, v[e]);
+            for (int e = 0; e < 4; ++e) {
+                if (a.l0_thresh >= 0.f && fabsf(v[e]) < a.l0_thresh * step_morph) v[e] = 0.f;
+                if (a.l1_thresh >= 0.f) {
+                    const float mag = fabsf(v[e]) - a.l1_thresh * step_morph;
+                    v[e] = (v[e] > 0.f ? 1.f : (v[e] < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
                 }
+                if (v[e] < 0.f || sweep_level(y, x + e, cy, cx) > lstop) v[e] = 0.f;
+                anynan |= (v[e] != v[e]);
+                vmax = fmaxf(vmax, v[e]);
             }
-            vreg[j] = make_float4(v[0], v[1], v[2], v[3]);
+            lds_store4(p, make_float4(v[0], v[1], v[2], v[3]));
         }
         float norm = wave_max(vmax);
         if (__any(anynan)) norm = __builtin_nanf("");
         if (!(norm > 0.f) || isinf(norm)) stat |= SCARLET_STATUS_NONFINITE;
-        // normalise, store, convergence sums against the previous iteration (buffer c0)
+        wave_sync();
+        // normalise, store, convergence sums against the previous iteration (buffer c0, L2-resident)
+        const float4 *last4 = reinterpret_cast<const float4 *>(min_g + (size_t)k * HW);
         float4 *out4 = reinterpret_cast<float4 *>(mout_g + (size_t)k * HW);
-        double d2 = 0, n2 = 0;
-#pragma unroll
-        for (int j = 0; j < GPW; ++j) {
-            const int g = lane + j * SC_WAVE;
-            if (g < ngroups) {
-                const float4 v4 = vreg[j], l = lastv[j];
-                const float4 o = make_float4(v4.x / norm, v4.y / norm, v4.z / norm, v4.w / norm);
-                out4[g] = o;
-                const float e0 = l.x - o.x, e1 = l.y - o.y, e2 = l.z - o.z, e3 = l.w - o.w;
-                d2 += (double)(e0 * e0) + (double)(e1 * e1) + (double)(e2 * e2) + (double)(e3 * e3);
-                n2 += (double)(o.x * o.x) + (double)(o.y * o.y) + (double)(o.z * o.z) + (double)(o.w * o.w);
-            }
+        float d2f = 0.f, n2f = 0.f;                      // 64 float terms per lane, then f64 across lanes
+#pragma unroll 4
+        for (int g = lane; g < ngroups; g += SC_WAVE) {
+            const int y = g / gpr, x = (g - y * gpr) << 2;
+            const float4 l = last4[g];
+            const float4 v4 = lds_load4(t.m + y * LW + x);
+            const float4 o = make_float4(v4.x / norm, v4.y / norm, v4.z / norm, v4.w / norm);
+            out4[g] = o;
+            const float e0 = l.x - o.x, e1 = l.y - o.y, e2 = l.z - o.z, e3 = l.w - o.w;
+            d2f += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+            n2f += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
         }
+        double d2 = (double)d2f, n2 = (double)n2f;
         d2 = wave_sum(d2); n2 = wave_sum(n2);
         double d2s = 0, n2s = 0;
         if (lane < B) {

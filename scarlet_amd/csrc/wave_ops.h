@@ -131,7 +131,7 @@ __device__ __forceinline__ Walker<T> make_walker(bool xmajor, int e, int H, int 
 }
 
 template <typename T>
-__device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thresh)
+__device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thresh, int *last_level = nullptr)
 {
     const int H = t.H, W = t.W, LW = t.LW;
     T *m = t.m;
@@ -166,24 +166,50 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         const T t1 = q.c1 > 0 ? q.x1 * q.c1 : (T)0, t3 = q.c3 > 0 ? q.x3 * q.c3 : (T)0;
         const T t4 = q.c4 > 0 ? q.x4 * q.c4 : (T)0;
         const T cap = ((q.x2 * q.c2 + t1) + (t3 + t4)) * inv * one_minus;
-        if (q.act && cap < q.x0) m[q.p] = cap;
+        const bool lower = q.act && cap < q.x0;
+        if (lower) m[q.p] = cap;
+        return q.act && (lower ? cap : q.x0) > (T)0;          // does this pixel end up positive?
     };
+    // Early exit (only when the caller applies positivity afterwards, as the source pipeline
+    // does, and 0 <= thresh <= 1): every closer neighbour of a level-l pixel lies on levels
+    // l-1, l-2 or l-3, and the cap is a non-negative combination of them.  Once three
+    // consecutive levels hold no positive value, every later pixel ends up <= 0 and is
+    // zeroed by prox_plus anyway -- the remaining levels need not be swept.  *last_level
+    // receives the last level that was computed; the caller zeroes everything beyond it.
+    const bool early = last_level != nullptr && thresh >= (T)0 && thresh <= (T)1;
+    int quiet = 0, done = Lall;
     for (int ell = 1; ell <= Lall; ell += 2) {
         {   // odd level
             const Px qa = gather(ell, wx1);
             const Px qb = gather(ell, wy1);
-            finish(qa);
-            finish(qb);
+            const bool pa = finish(qa);
+            const bool pb = finish(qb);
             wave_sync();
+            if (early) {
+                quiet = __any(pa || pb) ? 0 : quiet + 1;
+                if (quiet >= 3) { done = ell; break; }
+            }
         }
         if (ell + 1 <= Lall) {   // even level
             const Px qa = gather(ell + 1, wx0);
             const Px qb = gather(ell + 1, wy0);
-            finish(qa);
-            finish(qb);
+            const bool pa = finish(qa);
+            const bool pb = finish(qb);
             wave_sync();
+            if (early) {
+                quiet = __any(pa || pb) ? 0 : quiet + 1;
+                if (quiet >= 3) { done = ell + 1; break; }
+            }
         }
     }
+    if (last_level) *last_level = done;
+}
+
+// level of pixel (y, x) for a peak at (cy, cx): the sweep's topological level
+__device__ __forceinline__ int sweep_level(int y, int x, int cy, int cx)
+{
+    const int ay = y < cy ? cy - y : y - cy, ax = x < cx ? cx - x : x - cx;
+    return ay > ax ? 2 * ay + ax : 2 * ax + ay;
 }
 
 // ---------------------------------------------------------------- a16 flip symmetry
