@@ -11,20 +11,45 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- wave / block reductions
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = SC_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, SC_WAVE);
-    return v;
+// All-lane reductions over the 64-lane wave.  Within a 16-lane DPP row: two quad permutes
+// (lane^1, lane^2), row_half_mirror and row_mirror -- VALU-rate moves, no LDS crossbar;
+// across the four rows: v_readlane into SGPRs.  (__shfl_xor lowers to ds_bpermute, ~60+
+// cycles of latency per step on the critical path of every phase end.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = SC_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, SC_WAVE);
-    return v;
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float read_lane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+#define SC_DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define SC_DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define SC_DPP_HALF_MIRROR 0x141
+#define SC_DPP_MIRROR 0x140
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+    v += dpp_mov<SC_DPP_XOR1>(v);
+    v += dpp_mov<SC_DPP_XOR2>(v);
+    v += dpp_mov<SC_DPP_HALF_MIRROR>(v);
+    v += dpp_mov<SC_DPP_MIRROR>(v);
+    return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = SC_WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, SC_WAVE));
-    return v;
+    v = fmaxf(v, dpp_mov<SC_DPP_XOR1>(v));
+    v = fmaxf(v, dpp_mov<SC_DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<SC_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<SC_DPP_MIRROR>(v));
+    return fmaxf(fmaxf(read_lane(v, 0), read_lane(v, 16)), fmaxf(read_lane(v, 32), read_lane(v, 48)));
 }
 
 // Block-wide sum of a double; `red` is SC_NWAVES doubles of LDS.  All threads get the result.

@@ -6,9 +6,9 @@
 //
 //   phase 0  ALL global loads of the iteration are issued first (morph tiles and images,
 //            16 B/lane); morph tiles -> LDS, morph Gram S S^T on the fly            [a6]
-//   eig      Lipschitz constants: float32 Jacobi for the dominant eigenvector +
-//            float64 Rayleigh quotient, one lane each for S S^T and A A^T; the image
-//            loads are in flight meanwhile                                          [a6]
+//   eig      Lipschitz constants: largest root of the float64 characteristic polynomial
+//            (n <= 4; Newton from the trace), lanes 0/1 of wave 0 for S S^T and A A^T;
+//            the image loads are in flight meanwhile                                [a6]
 //   phase 1  model, residual, loss, G, SED gradient sums from the prefetched images;
 //            morphology step applied in place in LDS                                [a1-a5, a7]
 //   phase 2  wave k runs the constraint pipeline of component k on its LDS tile and
@@ -20,6 +20,7 @@
 // bytes of SURVEY.md 8d.  The unfused kernels of engine.h remain the general path
 // (larger images, approximate_L).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "prox_ops.h"
 #include "wave_ops.h"
@@ -53,82 +54,49 @@ __device__ __forceinline__ float4 lds_load4(const float *p)
     return make_float4(a.x, a.y, b.x, b.y);
 }
 
-// Largest eigenvalue of a symmetric PSD n x n matrix (n <= N <= 4) by ONE lane, all in
-// registers: cyclic Jacobi in float32 accumulating the eigenvectors, then the Rayleigh
-// quotient of the dominant eigenvector with the float64 matrix.  The quotient's error is
-// quadratic in the eigenvector error, i.e. <= ~1e-7 relative in the worst (degenerate)
-// case and ~1e-12 typically -- at float32 latencies instead of a float64 Jacobi chain.
+// Largest eigenvalue of a symmetric PSD n x n matrix, n <= 4, from its characteristic
+// polynomial in float64:  p(x) = x^4 - c1 x^3 + c2 x^2 - c3 x + c4  with ck = the sum of the
+// k x k principal minors (rows/columns >= n count as zero).  All roots are real and
+// p, p', p'' > 0 to the right of the largest one, so Newton's iteration started at the
+// trace (>= lambda_max) decreases monotonically onto it.  ~10 x fewer dependent
+// instructions than a Jacobi sweep; the root's conditioning is that of the eigenvalue
+// (error ~1e-16 separated, ~1e-8 relative for a double top eigenvalue).
 // Replaces np.linalg.eigvals(...).max() of blend.py:216-218.
-template <int N>
-__device__ inline double lambda_max_rayleigh(const double *Ain, int n, int ld)
+__device__ inline double lambda_max_charpoly4(const double *A, int n, int ld)
 {
-    float A[N][N], V[N][N];
+    double m[4][4];
 #pragma unroll
-    for (int i = 0; i < N; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            A[i][j] = (i < n && j < n) ? (float)Ain[i * ld + j] : 0.f;
-            V[i][j] = i == j ? 1.f : 0.f;
-        }
-    for (int sweep = 0; sweep < 8; ++sweep) {
-        float off = 0.f, diag = 0.f;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            diag += A[i][i] * A[i][i];
-#pragma unroll
-            for (int j = i + 1; j < N; ++j) off += A[i][j] * A[i][j];
-        }
-        if (off <= 1e-13f * diag) break;
-#pragma unroll
-        for (int p = 0; p < N - 1; ++p)
-#pragma unroll
-            for (int q = p + 1; q < N; ++q) {
-                const float apq = A[p][q];
-                if (apq != 0.f) {
-                    const float th = (A[q][q] - A[p][p]) / (2.f * apq);
-                    const float tf = (th >= 0.f ? 1.f : -1.f) / (fabsf(th) + sqrtf(th * th + 1.f));
-                    const float c = 1.0f / sqrtf(tf * tf + 1.f), sn = tf * c;
-#pragma unroll
-                    for (int r = 0; r < N; ++r) {
-                        const float arp = A[r][p], arq = A[r][q];
-                        A[r][p] = c * arp - sn * arq; A[r][q] = sn * arp + c * arq;
-                    }
-#pragma unroll
-                    for (int r = 0; r < N; ++r) {
-                        const float apr = A[p][r], aqr = A[q][r];
-                        A[p][r] = c * apr - sn * aqr; A[q][r] = sn * apr + c * aqr;
-                    }
-#pragma unroll
-                    for (int r = 0; r < N; ++r) {
-                        const float vrp = V[r][p], vrq = V[r][q];
-                        V[r][p] = c * vrp - sn * vrq; V[r][q] = sn * vrp + c * vrq;
-                    }
-                }
-            }
+        for (int j = 0; j < 4; ++j) m[i][j] = (i < n && j < n) ? A[i * ld + j] : 0.0;
+    const double a = m[0][0], b = m[1][1], c = m[2][2], d = m[3][3];
+    const double e = m[0][1], f = m[0][2], g = m[0][3], h = m[1][2], k = m[1][3], l = m[2][3];
+    const double c1 = (a + b) + (c + d);
+    // 2 x 2 minors of rows (0,1) and of rows (2,3), column pairs 01 02 03 12 13 23
+    const double p01 = a * b - e * e, p02 = a * h - e * f, p03 = a * k - e * g;
+    const double p12 = e * h - b * f, p13 = e * k - b * g, p23 = f * k - h * g;
+    const double q01 = f * k - g * h, q02 = f * l - g * c, q03 = f * d - g * l;
+    const double q12 = h * l - k * c, q13 = h * d - k * l, q23 = c * d - l * l;
+    const double c2 = p01 + (a * c - f * f) + (a * d - g * g) + (b * c - h * h) + (b * d - k * k) + q23;
+    // 3 x 3 principal minors
+    const double d012 = c * p01 - h * p02 + f * p12;          // rows/cols 0,1,2 (expansion along row 2)
+    const double d013 = d * p01 - k * p03 + g * p13;          // rows/cols 0,1,3 (along row 3)
+    const double d023 = a * q23 - f * (f * d - l * g) + g * (f * l - c * g);
+    const double d123 = b * q23 - h * (h * d - l * k) + k * (h * l - c * k);
+    const double c3 = (d012 + d013) + (d023 + d123);
+    // Laplace expansion over rows (0,1) x rows (2,3)
+    const double c4 = p01 * q23 - p02 * q13 + p03 * q12 + p12 * q03 - p13 * q02 + p23 * q01;
+    double x = c1;
+    if (!(x > 0.0)) return x;                                  // zero / NaN matrix: 1/L is inf / NaN as in the reference
+    for (int it = 0; it < 64; ++it) {
+        const double pv = (((x - c1) * x + c2) * x - c3) * x + c4;
+        const double dv = ((4.0 * x - 3.0 * c1) * x + 2.0 * c2) * x - c3;
+        if (!(pv > 0.0) || !(dv > 0.0)) break;                 // at (or, by rounding, just past) the root
+        const double dx = pv / dv;
+        x -= dx;
+        if (dx <= 1e-15 * x) break;
     }
-    int best = 0;
-    float bestv = A[0][0];            // (static indexing only: dynamic indices would spill to scratch)
-#pragma unroll
-    for (int i = 1; i < N; ++i) if (A[i][i] > bestv) { bestv = A[i][i]; best = i; }
-    double v[N];
-#pragma unroll
-    for (int r = 0; r < N; ++r) {
-        float x = V[r][0];
-#pragma unroll
-        for (int j = 1; j < N; ++j) x = (best == j) ? V[r][j] : x;
-        v[r] = (double)x;
-    }
-    double num = 0, den = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        if (i < n) {
-            double row = 0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) if (j < n) row += Ain[i * ld + j] * v[j];
-            num += v[i] * row; den += v[i] * v[i];
-        }
-    }
-    return num / den;
+    return x;
 }
 
 template <int KM, int BM>
@@ -144,6 +112,7 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
     constexpr int NG = KM * (KM + 1) / 2;
     constexpr int NP = 1 + KM * BM;
     constexpr int GPT = 4;                       // float4 groups per thread (H, W <= 64)
+    constexpr int GPW = 16;                      // float4 groups per lane in the per-wave passes
     constexpr bool PREFETCH = (KM <= 4);         // image prefetch needs 16*BM/4 more VGPRs
     __shared__ double red[SC_NWAVES][NP > NG ? NP : NG];
     __shared__ double tot[NP > NG ? NP : NG];
@@ -188,6 +157,8 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
         }
     }
     for (int i = tid; i < K * B; i += SC_BLOCK) sed_s[(i / B) * BM + (i % B)] = sed_in[i];
+    const bool small_side = (K <= B);          // nonzero spectrum of A^T A == that of A A^T
+    __syncthreads();                           // sed_s visible
     float gram[NG];
 #pragma unroll
     for (int i = 0; i < NG; ++i) gram[i] = 0.f;
@@ -226,46 +197,37 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
     }
     __syncthreads();
     STAMP(1);
-    // assemble the two small Gram matrices in parallel (one entry per thread) ...
-    const bool small_side = (K <= B);          // nonzero spectrum of A^T A == that of A A^T
-    if (tid < K * K) {
-        const int k = tid / K, k2 = tid - k * K;
-        const int lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
-        const int go = lo * K - (lo * (lo - 1)) / 2 + (hi - lo);     // packed upper-triangle index
-        double r = 0;
+    // Lipschitz constants (blend.py:205-218): L_sed = lambda_max(S S^T) on lane 0,
+    // L_morph = lambda_max(A^T A) on lane 1 of wave 0 -- one instruction stream for both
+    if (wid == 0) {
+        if (lane < K * K) {
+            const int k = lane / K, k2 = lane - k * K;
+            const int lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
+            const int go = lo * K - (lo * (lo - 1)) / 2 + (hi - lo);     // packed upper-triangle index
+            double r = 0;
 #pragma unroll
-        for (int w = 0; w < SC_NWAVES; ++w) r += red[w][go];
-        mat[0][k * KM + k2] = r;
-    }
-    if (tid >= SC_WAVE && tid < SC_WAVE + (small_side ? K * K : B * B)) {
-        const int i = tid - SC_WAVE;
-        double r = 0;
-        if (small_side) {
-            const int k = i / K, k2 = i - k * K;
-            for (int b = 0; b < B; ++b) r += (double)sed_s[k * BM + b] * sed_s[k2 * BM + b];
-            mat[1][k * KM + k2] = r;
-        } else {
-            const int b = i / B, b2 = i - b * B;
-            for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
-            mat[1][b * BM + b2] = r;
+            for (int w = 0; w < SC_NWAVES; ++w) r += red[w][go];
+            mat[0][k * KM + k2] = r;
         }
-    }
-    __syncthreads();
-    // ... then one lane per matrix: blend.py:205-218, L_sed = lambda_max(S S^T) (wave 0),
-    // L_morph = lambda_max(A^T A) (wave 1)
-    if (tid == 0) {
-        const double L = (KM <= 4) ? lambda_max_rayleigh<(KM <= 4 ? KM : 1)>(mat[0], K, KM)
-                                   : jacobi_lambda_max(mat[0], K, KM);
-        step_s[0] = 1.0f / (float)L;
-        a.lipschitz[2 * s] = L;
-    } else if (tid == SC_WAVE) {
-        double L;
-        if (small_side)
-            L = (KM <= 4) ? lambda_max_rayleigh<(KM <= 4 ? KM : 1)>(mat[1], K, KM) : jacobi_lambda_max(mat[1], K, KM);
-        else
-            L = jacobi_lambda_max(mat[1], B, BM);
-        step_s[1] = 1.0f / (float)L;
-        a.lipschitz[2 * s + 1] = L;
+        if (lane < (small_side ? K * K : B * B)) {
+            double r = 0;
+            if (small_side) {
+                const int k = lane / K, k2 = lane - k * K;
+                for (int b = 0; b < B; ++b) r += (double)sed_s[k * BM + b] * sed_s[k2 * BM + b];
+                mat[1][k * KM + k2] = r;
+            } else {
+                const int b = lane / B, b2 = lane - b * B;
+                for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
+                mat[1][b * BM + b2] = r;
+            }
+        }
+        wave_sync();
+        if (lane < 2) {
+            const int n = (lane == 0 || small_side) ? K : B, ld = (lane == 0 || small_side) ? KM : BM;
+            const double L = n <= 4 ? lambda_max_charpoly4(mat[lane], n, ld) : jacobi_lambda_max(mat[lane], n, ld);
+            step_s[lane] = 1.0f / (float)L;
+            a.lipschitz[2 * s + lane] = L;
+        }
     }
     __syncthreads();
     STAMP(2);
@@ -375,56 +337,123 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
             }
             STAMP(8);
             const bool none = (dy != dy);
-            wave_symmetry(t, cy, cx, none ? SCARLET_SYM_SOFT : SCARLET_SYM_KSPACE, 1.0f, dy, dx, false, 0.f, vec);
+            wave_symmetry(t, cy, cx, none ? SCARLET_SYM_SOFT : SCARLET_SYM_KSPACE, 1.0f, dy, dx, false, 0.f, vec,
+                          (a.stamps && wid == 0) ? a.stamps + (size_t)s * 16 + 12 : nullptr);
         }
         STAMP(9);
-        int lstop = 1 << 30;            // last sweep level computed; pixels beyond are <= 0 -> 0
+        int lstop = 1 << 30;            // last sweep level computed (early exit); pixels beyond are <= 0 -> 0
         if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f, &lstop);
         STAMP(10);
         if (lane == 0) { a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
-        // sparsity, positivity, max (update.py:71-82, 27-32, 62-65): one pass over the LDS tile.
-        // (Two short passes through LDS instead of 128 live registers: the register version
-        // spilled and ran 2.5x slower.)
-        float vmax = -INFINITY;
-        bool anynan = false;
-#pragma unroll 4
-        for (int g = lane; g < ngroups; g += SC_WAVE) {
-            const int y = g / gpr, x = (g - y * gpr) << 2;
-            float *p = t.m + y * LW + x;
-            const float4 v4 = lds_load4(p);
-            float v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (a.l0_thresh >= 0.f && fabsf(v[e]) < a.l0_thresh * step_morph) v[e] = 0.f;
-                if (a.l1_thresh >= 0.f) {
-                    const float mag = fabsf(v[e]) - a.l1_thresh * step_morph;
-                    v[e] = (v[e] > 0.f ? 1.f : (v[e] < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
-                }
-                if (v[e] < 0.f || sweep_level(y, x + e, cy, cx) > lstop) v[e] = 0.f;
-                anynan |= (v[e] != v[e]);
-                vmax = fmaxf(vmax, v[e]);
-            }
-            lds_store4(p, make_float4(v[0], v[1], v[2], v[3]));
-        }
-        float norm = wave_max(vmax);
-        if (__any(anynan)) norm = __builtin_nanf("");
-        if (!(norm > 0.f) || isinf(norm)) stat |= SCARLET_STATUS_NONFINITE;
-        wave_sync();
-        // normalise, store, convergence sums against the previous iteration (buffer c0, L2-resident)
+        // ---- sparsity, positivity (update.py:71-82, 27-32), normalisation (update.py:62-65),
+        // store, convergence sums against the previous iteration: ONE pass over the LDS tile.
+        // The previous morphology (buffer c0) is loaded up front, all 16 B/lane requests in
+        // flight together: loads queued behind this pass's own stores would wait for them.
         const float4 *last4 = reinterpret_cast<const float4 *>(min_g + (size_t)k * HW);
-        float4 *out4 = reinterpret_cast<float4 *>(mout_g + (size_t)k * HW);
-        float d2f = 0.f, n2f = 0.f;                      // 64 float terms per lane, then f64 across lanes
-#pragma unroll 4
-        for (int g = lane; g < ngroups; g += SC_WAVE) {
-            const int y = g / gpr, x = (g - y * gpr) << 2;
-            const float4 l = last4[g];
-            const float4 v4 = lds_load4(t.m + y * LW + x);
-            const float4 o = make_float4(v4.x / norm, v4.y / norm, v4.z / norm, v4.w / norm);
-            out4[g] = o;
-            const float e0 = l.x - o.x, e1 = l.y - o.y, e2 = l.z - o.z, e3 = l.w - o.w;
-            d2f += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-            n2f += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+        float4 lastv[GPW];
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) {
+            const int g = lane + j * SC_WAVE;
+            lastv[j] = g < ngroups ? last4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const bool cut = lstop < (1 << 30);
+        float l0 = a.l0_thresh >= 0.f ? a.l0_thresh * step_morph : -1.f;
+        float l1 = a.l1_thresh >= 0.f ? a.l1_thresh * step_morph : -1.f;
+        auto sparse = [&](float v) {
+            if (l0 >= 0.f && fabsf(v) < l0) v = 0.f;
+            if (l1 >= 0.f) {
+                const float mag = fabsf(v) - l1;
+                v = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
+            }
+            return v;
+        };
+        // lane -> (row, float4 group) walk without divisions: +64 groups per step
+        const int dyq = SC_WAVE / gpr, dxq = SC_WAVE - dyq * gpr;
+        const int y0 = lane / gpr, x0 = lane - y0 * gpr;
+        float norm;
+        if (a.monotonic) {
+            // after the sweep no pixel exceeds the peak pixel (each is capped by a convex
+            // combination of pixels closer to the peak) and the maps above are monotone:
+            // morph.max() is the processed peak value (a NaN elsewhere: see below)
+            norm = sparse(t.m[cy * LW + cx]);
+            if (norm < 0.f) norm = 0.f;
+        } else {
+            float vmax = -INFINITY;
+            bool anynan = false;
+            int y = y0, xq = x0;
+            for (int g = lane; g < ngroups; g += SC_WAVE) {
+                float *p = t.m + y * LW + (xq << 2);
+                float4 v = lds_load4(p);
+                v.x = sparse(v.x); v.y = sparse(v.y); v.z = sparse(v.z); v.w = sparse(v.w);
+                v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
+                v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                anynan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+                vmax = fmaxf(fmaxf(vmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                lds_store4(p, v);
+                y += dyq; xq += dxq;
+                if (xq >= gpr) { xq -= gpr; ++y; }
+            }
+            norm = wave_max(vmax);
+            if (__any(anynan)) norm = __builtin_nanf("");
+            l0 = -1.f; l1 = -1.f;                       // applied
+            wave_sync();
+        }
+        const bool regular = norm > 0.f && !isinf(norm);             // else: the reference's 0/0, x/inf, NaN results
+        const float rnorm = 1.0f / norm;
+        float4 *out4 = reinterpret_cast<float4 *>(mout_g + (size_t)k * HW);
+        float d2f = 0.f, n2f = 0.f;                      // <= 64 float terms per lane, then f64 across lanes
+        // CUT: zero beyond the sweep's last level; GEN: thresholds and/or an irregular norm
+        auto final_pass = [&](auto cut_c, auto gen_c) {
+            constexpr bool CUT = decltype(cut_c)::value, GEN = decltype(gen_c)::value;
+            int y = y0, xq = x0;
+#pragma unroll
+            for (int j = 0; j < GPW; ++j) {
+                const int g = lane + j * SC_WAVE;
+                if (g < ngroups) {
+                    const float4 v4 = lds_load4(t.m + y * LW + (xq << 2));
+                    const float4 l = lastv[j];
+                    float v[4] = {v4.x, v4.y, v4.z, v4.w}, o[4];
+                    const int ay = y < cy ? cy - y : y - cy;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (GEN) v[e] = sparse(v[e]);
+                        v[e] = v[e] < 0.f ? 0.f : v[e];                       // NaN stays NaN
+                        if (CUT) {
+                            const int x = (xq << 2) + e, ax = x < cx ? cx - x : x - cx;
+                            if (max(ax, ay) + ax + ay > lstop) v[e] = 0.f;
+                        }
+                        if (GEN && !regular) o[e] = v[e] / norm;
+                        else {
+                            // v / norm, correctly rounded (but for rare double roundings):
+                            // one Newton step on v * (1 / norm)
+                            const float q = v[e] * rnorm;
+                            o[e] = fmaf(fmaf(-q, norm, v[e]), rnorm, q);
+                        }
+                    }
+                    out4[g] = make_float4(o[0], o[1], o[2], o[3]);
+                    const float e0 = l.x - o[0], e1 = l.y - o[1], e2 = l.z - o[2], e3 = l.w - o[3];
+                    d2f += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+                    n2f += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                }
+                y += dyq; xq += dxq;
+                if (xq >= gpr) { xq -= gpr; ++y; }
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);    // two groups in flight, not sixteen (VGPRs)
+            }
+        };
+        using std::true_type; using std::false_type;
+        if (regular && l0 < 0.f && l1 < 0.f) {
+            if (cut) final_pass(true_type{}, false_type{}); else final_pass(false_type{}, false_type{});
+        } else {
+            final_pass(true_type{}, true_type{});
+        }
+        if (__any(n2f != n2f) && norm == norm) {
+            // a NaN pixel away from the peak: np.max is NaN and the reference's morph becomes NaN everywhere
+            norm = __builtin_nanf("");
+            const float4 nan4 = make_float4(norm, norm, norm, norm);
+            for (int g = lane; g < ngroups; g += SC_WAVE) out4[g] = nan4;
+            d2f = norm; n2f = norm;
+        }
+        if (!(norm > 0.f) || isinf(norm)) stat |= SCARLET_STATUS_NONFINITE;
         double d2 = (double)d2f, n2 = (double)n2f;
         d2 = wave_sum(d2); n2 = wave_sum(n2);
         double d2s = 0, n2s = 0;
@@ -441,6 +470,7 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
         if (lane == 0) {
             conv_s[k][0] = d2s; conv_s[k][1] = n2s; conv_s[k][2] = d2; conv_s[k][3] = n2;
             if (stat) atomicOr(&a.status[s], stat);
+            if (a.stamps && wid == 0) a.stamps[(size_t)s * 16 + 11] = (long long)__builtin_amdgcn_s_memtime();
         }
     }
     __syncthreads();

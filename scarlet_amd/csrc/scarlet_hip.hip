@@ -840,7 +840,8 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
     f.centroid_psf = b->centroid_psf; f.centroid_P = b->centroid_P; f.e_rel2 = e_rel * e_rel;
     // diagnostics: SCARLET_STAMPS=1 writes phase stamps into the (otherwise unused) partials area
     f.stamps = (getenv("SCARLET_STAMPS") && n_partials(b->K, b->B) >= 16) ? (long long *)ws_partials(b) : nullptr;
-    const size_t lds = fused_lds_bytes(b);
+    // experiment knob: SCARLET_PAD_LDS=<bytes> lowers the number of co-resident workgroups
+    const size_t lds = fused_lds_bytes(b) + (getenv("SCARLET_PAD_LDS") ? (size_t)atoi(getenv("SCARLET_PAD_LDS")) : 0);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_ITERATE(KM_, BM_)                                                                       \
     do {                                                                                               \

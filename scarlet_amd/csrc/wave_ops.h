@@ -177,7 +177,7 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     // zeroed by prox_plus anyway -- the remaining levels need not be swept.  *last_level
     // receives the last level that was computed; the caller zeroes everything beyond it.
     const bool early = last_level != nullptr && thresh >= (T)0 && thresh <= (T)1;
-    int quiet = 0, done = Lall;
+    int quiet = 0, done = 1 << 30;               // 1 << 30: swept to the end
     for (int ell = 1; ell <= Lall; ell += 2) {
         {   // odd level
             const Px qa = gather(ell, wx1);
@@ -240,8 +240,9 @@ __device__ inline void wave_flip_symmetry(const TileT<T> &t, const SymWindow &s,
 // {r, 4+r, 8+r, 12+r} and the Hankel operand is simply read at the matching index.
 // vec: LDS floats, 2*64 (av) + 2*64 (bv) + 2*64 (cv) + 64 (zv) per wave.
 __device__ inline void wave_kspace_symmetry(const Tile &t, const SymWindow &s, double dy, double dx,
-                                            float *vec)
+                                            float *vec, long long *dbg = nullptr)
 {
+#define KS_STAMP(i) do { if (dbg && lane_id() == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     float *m = t.m;
     const int LW = t.LW;
     const int h = s.h, w = s.w, ry = h / 2, rx = w / 2;
@@ -273,6 +274,7 @@ __device__ inline void wave_kspace_symmetry(const Tile &t, const SymWindow &s, d
         }
         av[q] = va; bv[q] = vb; cv[q] = vc;
     }
+    KS_STAMP(0);
     const float sy = (Fy & 1) ? 0.f : (float)(s2y / Fy);
     const bool rank1 = sy != 0.f;
     // rank-1 term: v[j] = sum_i (-1)^(i-ry) X[i][j]; z = C v
@@ -294,6 +296,7 @@ __device__ inline void wave_kspace_symmetry(const Tile &t, const SymWindow &s, d
         zv[lane] = z;
         wave_sync();
     }
+    KS_STAMP(1);
     const int lr = lane & 15, lq = lane >> 4;
     // GEMM 1: T = Xw . Hankel(bv), all tiles in registers
     f32x4 T[4][4];
@@ -319,23 +322,35 @@ __device__ inline void wave_kspace_symmetry(const Tile &t, const SymWindow &s, d
                     if (tc < ntc) T[tr][tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tr], b[tc], T[tr][tc], 0, 0, 0);
             }
     }
-    // GEMM 2: Y = Hankel(av) . T, one output tile at a time, epilogue in place
+    KS_STAMP(2);
+    // GEMM 2: Y = Hankel(av) . T, one tile ROW at a time: the 16 Hankel operands of the row are
+    // read once, the row's (up to) four output tiles accumulate in independent registers so
+    // that consecutive MFMAs never wait on each other; epilogue in place.
 #pragma unroll
     for (int tr = 0; tr < 4; ++tr) {
         if (tr >= ntr) continue;
+        float areg[4][4];
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                areg[tk][r] = tk < ntr ? av[(tr << 4) + lr + (tk << 4) + 4 * lq + r] : 0.f;
+        f32x4 acc[4];
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) acc[tc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk) {
+            if (tk >= ntr) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc)
+                    if (tc < ntc)
+                        acc[tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[tk][r], T[tk][tc][r], acc[tc], 0, 0, 0);
+        }
 #pragma unroll
         for (int tc = 0; tc < 4; ++tc) {
             if (tc >= ntc) continue;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tk = 0; tk < 4; ++tk) {
-                if (tk >= ntr) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a = av[(tr << 4) + lr + (tk << 4) + 4 * lq + r];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, T[tk][tc][r], acc, 0, 0, 0);
-                }
-            }
             const int jcol = (tc << 4) + lr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -343,7 +358,7 @@ __device__ inline void wave_kspace_symmetry(const Tile &t, const SymWindow &s, d
                 if (i < h && jcol < w) {
                     float *p = &m[(s.y0 + i) * LW + s.x0 + jcol];
                     const float x = *p;
-                    float y2 = acc[r];
+                    float y2 = acc[tc][r];
                     if (rank1) y2 += (((i - ry) & 1) ? -sy : sy) * zv[jcol];
                     *p = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
                 }
@@ -354,7 +369,8 @@ __device__ inline void wave_kspace_symmetry(const Tile &t, const SymWindow &s, d
 }
 
 __device__ inline void wave_symmetry(const Tile &t, int cy, int cx, int algorithm, float strength,
-                                     double dy, double dx, bool use_fill, float fill, float *vec)
+                                     double dy, double dx, bool use_fill, float fill, float *vec,
+                                     long long *dbg = nullptr)
 {
     SymWindow s = sym_window(t.H, t.W, cy, cx);
     if (algorithm & SCARLET_SYM_FULL_WINDOW) {   // bare operator on the whole array (operator.py:231-288)
@@ -363,7 +379,7 @@ __device__ inline void wave_symmetry(const Tile &t, int cy, int cx, int algorith
     }
     if (algorithm == SCARLET_SYM_KSPACE) {
         if (s.centered) return;
-        wave_kspace_symmetry(t, s, dy, dx, vec);
+        wave_kspace_symmetry(t, s, dy, dx, vec, dbg);
     } else {
         wave_flip_symmetry<float>(t, s, algorithm == SCARLET_SYM_SDSS, strength);
     }

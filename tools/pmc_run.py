@@ -1,0 +1,14 @@
+"""Small driver for rocprofv3 --pmc passes: 3 warm-up + 2 measured iterations on 10k scenes."""
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from scarlet_amd import synth
+from scarlet_amd.batch import BlendBatch
+S = int(os.environ.get("PMC_SCENES", "10000"))
+d = synth.make_batch(0, 512)
+reps = (S + 511) // 512
+imgs = np.tile(d["images"], (reps, 1, 1, 1))[:S]; cen = np.tile(d["centers"], (reps, 1, 1))[:S]
+b = BlendBatch(imgs, cen)
+b.init_extended(np.ones(5) * .1)
+b.fit(5, e_rel=0, check_every=0)
+torch.cuda.synchronize()

@@ -20,5 +20,10 @@ dt = np.diff(st[:, :7], axis=1)
 if st[:, 10].any():
     print("P2 wave0: pre-sym %d  sym %d  sweep %d  tail %d" % ((st[:, 8] - st[:, 4]).mean(), (st[:, 9] - st[:, 8]).mean(),
           (st[:, 10] - st[:, 9]).mean(), (st[:, 5] - st[:, 10]).mean()))
+if st[:, 11].any():
+    ok = st[:, 12] > 0
+    print("sym wave0: vectors %d  rank1 %d  gemm1 %d  gemm2 %d  (n=%d)" % ((st[ok, 12] - st[ok, 8]).mean(), (st[ok, 13] - st[ok, 12]).mean(),
+          (st[ok, 14] - st[ok, 13]).mean(), (st[ok, 9] - st[ok, 14]).mean(), ok.sum()))
+    print("P2 wave0 own tail:", (st[:, 11] - st[:, 10]).mean().round(0))
 print("phase cycles mean:", dt.mean(axis=0).round(0), " total", (st[:, 6] - st[:, 0]).mean())
 print("phase cycles p90 :", np.percentile(dt, 90, axis=0).round(0))
