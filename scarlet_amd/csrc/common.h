@@ -52,6 +52,29 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(read_lane(v, 0), read_lane(v, 16)), fmaxf(read_lane(v, 32), read_lane(v, 48)));
 }
 
+// Sum of N independent float values over the wave, entirely in DPP adds (six per value):
+// xor-butterfly inside each 16-lane row, then row_bcast:15 / row_bcast:31 chain the four
+// rows.  Only the lanes of the LAST row (48..63) hold the totals afterwards.
+#define SC_DPP_BCAST15 0x142
+#define SC_DPP_BCAST31 0x143
+template <int N>
+__device__ __forceinline__ void wave_sum_lastrow(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<SC_DPP_XOR1>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<SC_DPP_XOR2>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<SC_DPP_HALF_MIRROR>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<SC_DPP_MIRROR>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i)     // rows 1 and 3 receive lane 15 of the row before
+        v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), SC_DPP_BCAST15, 0xa, 0xf, false));
+#pragma unroll
+    for (int i = 0; i < N; ++i)     // rows 2 and 3 receive lane 31 (= rows 0 + 1)
+        v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), SC_DPP_BCAST31, 0xc, 0xf, false));
+}
+
 // Block-wide sum of a double; `red` is SC_NWAVES doubles of LDS.  All threads get the result.
 __device__ __forceinline__ double block_sum(double v, double *red) {
     v = wave_sum(v);

@@ -1,0 +1,638 @@
+// fused2.h -- k_iterate2: the fused iteration of fused.h with EIGHT waves per scene.
+//
+// The constraint chain of one component is a long dependent sequence (k-space symmetry
+// GEMMs -> radial sweep -> normalisation); with four waves per scene and LDS limiting a CU
+// to two scenes, each SIMD holds two waves and sits idle ~45 % of the time waiting on LDS /
+// MFMA / HBM latencies (profiles/r01_notes.md).  LDS cannot hold a third scene, so the
+// second lever is used: the same two scenes per CU run as 2 x 8 waves (four per SIMD, 128
+// VGPRs each) and every component is served by a PAIR of waves (wave k and wave k + 4,
+// which share SIMD k):
+//
+//   phases 0/1   pixel-parallel over 512 threads (two float4 groups per thread)
+//   k-space symmetry  vectors: 64 entries per wave; T = X B and Y = A T split by column
+//                tiles (wave h owns tiles h, h + 2) -- T never leaves the accumulators
+//   sweep        wave k alone (its partner waits at the barrier and costs no issue slots)
+//   tail         float4 groups split between the pair
+//
+// The pair is synchronised with workgroup barriers placed outside all divergent code, so
+// every wave executes the same number of them.  Used when K <= 4 (four pairs); other
+// shapes run k_iterate.  Same reference rows as fused.h.
+#pragma once
+#include "fused.h"
+
+#define SC_FB2 512
+#define SC_NW2 (SC_FB2 / SC_WAVE)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define SC_PAIR_VEC_FLOATS 512       // av, bv, cv (128 each) + one zv (64) per wave of the pair
+
+// ---- k-space symmetry, split over a pair of waves (see wave_kspace_symmetry for the maths)
+struct KsGeom { int h, w, ry, rx, ntr, ntc, wp, Fy, Fx; };
+__device__ __forceinline__ KsGeom ks_geom(const SymWindow &s)
+{
+    KsGeom g;
+    g.h = s.h; g.w = s.w; g.ry = s.h / 2; g.rx = s.w / 2;
+    g.ntr = round16(s.h) >> 4; g.wp = round16(s.w); g.ntc = g.wp >> 4;
+    g.Fy = dev_next_fast_len(2 * s.h + 10);
+    g.Fx = dev_next_fast_len(2 * s.w + 10);
+    while (g.Fx & 1) g.Fx = dev_next_fast_len(g.Fx + 1);
+    return g;
+}
+
+// Hankel vectors: this wave fills entries q = lane + 64 * half.  Returns s = sin(2 pi dy) / Fy
+// (0 for odd Fy), the coefficient of the rank-1 term.
+__device__ inline float pair_ks_vectors(const KsGeom &g, double dy, double dx, float *vec, int half)
+{
+    float *av = vec, *bv = vec + 128, *cv = vec + 256;
+    const double s2y = sinpi(2.0 * dy), s2x = sinpi(2.0 * dx), c2x = cospi(2.0 * dx);
+    const int q = lane_id() + SC_WAVE * half;
+    float va = 0.f, vb = 0.f, vc = 0.f;
+    if (q <= 2 * (g.h - 1)) {
+        const int n = q - 2 * g.ry;
+        const double tt = (double)n - 2.0 * dy;
+        const double sn = sinpi(tt / g.Fy), cs = cospi(tt / g.Fy);
+        const double spt = (n & 1) ? s2y : -s2y;
+        va = (float)(sn == 0.0 ? 1.0 : ((g.Fy & 1) ? spt / (g.Fy * sn) : spt * cs / (g.Fy * sn)));
+    }
+    if (q <= 2 * (g.w - 1)) {
+        const int n = q - 2 * g.rx;
+        const double tt = (double)n - 2.0 * dx;
+        const double sn = sinpi(tt / g.Fx), cs = cospi(tt / g.Fx);
+        const double spt = (n & 1) ? s2x : -s2x;
+        const double cpt = (n & 1) ? -c2x : c2x;
+        if (sn == 0.0) { vb = 1.f; vc = 0.f; }
+        else { vb = (float)(spt * cs / (g.Fx * sn)); vc = (float)(-(1.0 - cpt) * cs / (g.Fx * sn)); }
+    }
+    av[q] = va; bv[q] = vb; cv[q] = vc;
+    return (g.Fy & 1) ? 0.f : (float)(s2y / g.Fy);
+}
+
+// rank-1 term, part 1 (tile reads only): zv[j] = sum_i (-1)^(i-ry) X[i][j]
+__device__ inline void pair_ks_colsums(const Tile &t, const SymWindow &s, const KsGeom &g, float *zv)
+{
+    const int lane = lane_id();
+    float v = 0.f;
+    if (lane < g.w)
+        for (int i = 0; i < g.h; ++i) {
+            const float x = t.m[(s.y0 + i) * t.LW + s.x0 + lane];
+            v += ((i - g.ry) & 1) ? -x : x;
+        }
+    zv[lane] = lane < g.w ? v : 0.f;
+}
+// part 2 (needs the partner's half of cv): zv <- C zv
+__device__ inline void pair_ks_z(const KsGeom &g, const float *cv, float *zv)
+{
+    const int lane = lane_id();
+    wave_sync();
+    float z = 0.f;
+    if (lane < g.w)
+        for (int j2 = 0; j2 < g.w; ++j2) z += cv[lane + j2] * zv[j2];
+    wave_sync();
+    zv[lane] = z;
+    wave_sync();
+}
+
+// GEMM 1: T[:, tc] = Xw . Hankel(bv)[:, tc] for this wave's column tiles tc = half, half + 2
+__device__ inline void pair_ks_gemm1(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
+                                     int half, f32x4 (&T)[4][2])
+{
+    const float *m = t.m, *bv = vec + 128;
+    const int LW = t.LW, lane = lane_id(), lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) T[tr][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (half >= g.ntc) return;
+    // software pipeline: operands of step k0 + 4 are in flight while step k0 multiplies
+    float a[4], b[2], an[4], bn[2];
+    auto fetch = [&](int k0, float (&fa)[4], float (&fb)[2]) {
+        const int k = k0 + lq;
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr) {
+            const int i = (tr << 4) + lr;
+            fa[tr] = (tr < g.ntr && i < g.h && k < g.w) ? m[(s.y0 + i) * LW + s.x0 + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int tc = half + 2 * i;
+            fb[i] = tc < g.ntc ? bv[k + (tc << 4) + lr] : 0.f;
+        }
+    };
+    fetch(0, a, b);
+    for (int k0 = 0; k0 < g.wp; k0 += 4) {
+        if (k0 + 4 < g.wp) fetch(k0 + 4, an, bn);
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr)
+            if (tr < g.ntr) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (half + 2 * i < g.ntc)
+                        T[tr][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tr], b[i], T[tr][i], 0, 0, 0);
+            }
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr) a[tr] = an[tr];
+        b[0] = bn[0]; b[1] = bn[1];
+    }
+}
+
+// GEMM 2 + epilogue in place for this wave's column tiles
+__device__ inline void pair_ks_gemm2(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
+                                     const float *zv, int half, const f32x4 (&T)[4][2], float sy, bool rank1)
+{
+    float *m = t.m;
+    const float *av = vec;
+    const int LW = t.LW, lane = lane_id(), lr = lane & 15, lq = lane >> 4;
+    if (half >= g.ntc) return;
+#pragma unroll
+    for (int tr = 0; tr < 4; ++tr) {
+        if (tr >= g.ntr) continue;
+        float areg[4][4];
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                areg[tk][r] = tk < g.ntr ? av[(tr << 4) + lr + (tk << 4) + 4 * lq + r] : 0.f;
+        f32x4 acc[2];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk) {
+            if (tk >= g.ntr) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (half + 2 * i < g.ntc)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[tk][r], T[tk][i][r], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int tc = half + 2 * i;
+            if (tc >= g.ntc) continue;
+            const int jcol = (tc << 4) + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (tr << 4) + lq * 4 + r;
+                if (row < g.h && jcol < g.w) {
+                    float *p = &m[(s.y0 + row) * LW + s.x0 + jcol];
+                    const float x = *p;
+                    float y2 = acc[i][r];
+                    if (rank1) y2 += (((row - g.ry) & 1) ? -sy : sy) * zv[jcol];
+                    *p = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
+                }
+            }
+        }
+    }
+}
+
+template <int KM, int BM>
+__global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
+{
+    static_assert(KM <= 4, "one pair of waves per component");
+    extern __shared__ __align__(16) float lds[];
+    const int s = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, H = a.H, W = a.W, HW = H * W, LW = tile_stride(W);
+    const int tile_floats = H * LW;
+    float *tiles = lds;
+    float *vecs = lds + (size_t)K * tile_floats;
+    constexpr int NG = KM * (KM + 1) / 2;
+    constexpr int NP = 1 + KM * BM;
+    constexpr int GPT = 2;                       // float4 groups per thread in phases 0/1 (H, W <= 64)
+    constexpr int GPW = 8;                       // float4 groups per lane in the pair's final pass
+    __shared__ float red[SC_NW2][NP > NG ? NP : NG];      // per-wave partial sums
+    __shared__ double tot[NP > NG ? NP : NG];
+    __shared__ double mat[2][KM * KM > BM * BM ? KM * KM : BM * BM];
+    __shared__ float sed_s[KM * BM], sed_new[KM * BM];
+    __shared__ float step_s[2];
+    __shared__ double conv_s[KM][2], conv_m[KM][2][2];
+    __shared__ int lstop_s[KM];
+    __shared__ float nmax_s[KM][2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c0 = a.cur[s];
+    const float *min_g = a.morph[c0] + (size_t)s * K * HW;
+    float *mout_g = a.morph[1 - c0] + (size_t)s * K * HW;
+    const float *sed_in = a.sed[c0] + (size_t)s * K * B;
+    float *sed_out = a.sed[1 - c0] + (size_t)s * K * B;
+    const int it_new = a.it[s] + 1;
+    const int ngroups = HW >> 2, gpr = W >> 2;           // float4 groups, groups per row
+    const float *img = a.images + (size_t)s * B * HW;
+    const float *wgt = a.weights ? a.weights + (size_t)s * B * HW : nullptr;
+#define STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)s * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    STAMP(0);
+
+    // ---------------- phase 0: issue every global load, tiles -> LDS, Gram
+    float4 mreg[GPT][KM];
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+        const int g = tid + j * SC_FB2;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            mreg[j][k] = (g < ngroups && k < K) ? reinterpret_cast<const float4 *>(min_g + (size_t)k * HW)[g]
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // images: the first group's are requested now, the second group's when phase 1 starts
+    // (under the first group's arithmetic) -- 128 VGPRs do not hold both next to the accumulators
+    float4 ireg[GPT][BM];
+    auto load_images = [&](int j) {
+        const int g = tid + j * SC_FB2;
+#pragma unroll
+        for (int b = 0; b < BM; ++b)
+            ireg[j][b] = (g < ngroups && b < B) ? reinterpret_cast<const float4 *>(img + (size_t)b * HW)[g]
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    load_images(0);
+    for (int i = tid; i < K * B; i += SC_FB2) sed_s[(i / B) * BM + (i % B)] = sed_in[i];
+    const bool small_side = (K <= B);          // nonzero spectrum of A^T A == that of A A^T
+    __syncthreads();                           // sed_s visible
+    {
+        float gram[NG];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) gram[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            const int g = tid + j * SC_FB2;
+            if (g < ngroups) {
+                const int y = g / gpr, x = (g - y * gpr) << 2;
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) lds_store4(tiles + k * tile_floats + y * LW + x, mreg[j][k]);
+                int gi = 0;
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+#pragma unroll
+                    for (int k2 = k; k2 < KM; ++k2) {
+                        const float4 p = mreg[j][k], q = mreg[j][k2];
+                        gram[gi] += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
+                        ++gi;
+                    }
+            }
+        }
+        wave_sum_lastrow(gram);                 // float partials per wave, float64 across the waves
+        if (lane == SC_WAVE - 1) {
+            int gi = 0, go = 0;
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+#pragma unroll
+                for (int k2 = k; k2 < KM; ++k2) {
+                    if (k < K && k2 < K) red[wid][go++] = gram[gi];
+                    ++gi;
+                }
+        }
+    }
+    __syncthreads();
+    STAMP(1);
+    // Lipschitz constants (blend.py:205-218): L_sed = lambda_max(S S^T) on lane 0,
+    // L_morph = lambda_max(A^T A) on lane 1 of wave 0 -- one instruction stream for both
+    if (wid == 0) {
+        if (lane < K * K) {
+            const int k = lane / K, k2 = lane - k * K;
+            const int lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
+            const int go = lo * K - (lo * (lo - 1)) / 2 + (hi - lo);     // packed upper-triangle index
+            double r = 0;
+#pragma unroll
+            for (int w = 0; w < SC_NW2; ++w) r += (double)red[w][go];
+            mat[0][k * KM + k2] = r;
+        }
+        if (lane < (small_side ? K * K : B * B)) {
+            double r = 0;
+            if (small_side) {
+                const int k = lane / K, k2 = lane - k * K;
+                for (int b = 0; b < B; ++b) r += (double)sed_s[k * BM + b] * sed_s[k2 * BM + b];
+                mat[1][k * KM + k2] = r;
+            } else {
+                const int b = lane / B, b2 = lane - b * B;
+                for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
+                mat[1][b * BM + b2] = r;
+            }
+        }
+        wave_sync();
+        if (lane < 2) {
+            const int n = (lane == 0 || small_side) ? K : B, ld = (lane == 0 || small_side) ? KM : BM;
+            const double L = n <= 4 ? lambda_max_charpoly4(mat[lane], n, ld) : jacobi_lambda_max(mat[lane], n, ld);
+            step_s[lane] = 1.0f / (float)L;
+            a.lipschitz[2 * s + lane] = L;
+        }
+    }
+    __syncthreads();
+    STAMP(2);
+    const float step_sed = step_s[0], step_morph = step_s[1];
+
+    // ---------------- phase 1: gradient + morphology step in LDS
+    {
+        float sed[KM][BM];                     // wave-uniform: lives in SGPRs
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int b = 0; b < BM; ++b)
+                sed[k][b] = (k < K && b < B) ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+                                                   __builtin_bit_cast(int, sed_s[k * BM + b]))) : 0.f;
+        bool fixm[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) fixm[k] = (k < K) && a.fix_morph && a.fix_morph[(size_t)s * K + k];
+        // two pixels per instruction (v_pk_fma_f32): p = 0 holds pixels (0, 1) of the float4
+        // group, p = 1 pixels (2, 3); the SED gradient and loss accumulators stay paired
+        f32x2 dsed2[KM][BM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int b = 0; b < BM; ++b) dsed2[k][b] = (f32x2){0.f, 0.f};
+        f32x2 loss2 = {0.f, 0.f};
+        const f32x2 ws2 = {a.weight_scalar, a.weight_scalar};
+#pragma unroll
+        for (int j = 1; j < GPT; ++j) load_images(j);
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            const int g = tid + j * SC_FB2;
+            if (g < ngroups) {
+                const int y = g / gpr, x = (g - y * gpr) << 2;
+                f32x2 m2[KM][2], gm2[KM][2];
+#pragma unroll
+                for (int k = 0; k < KM; ++k) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < K) v = lds_load4(tiles + k * tile_floats + y * LW + x);
+                    m2[k][0] = (f32x2){v.x, v.y}; m2[k][1] = (f32x2){v.z, v.w};
+                    gm2[k][0] = (f32x2){0.f, 0.f}; gm2[k][1] = gm2[k][0];
+                }
+#pragma unroll
+                for (int b = 0; b < BM; ++b) {
+                    if (b < B) {
+                        const float4 iv = ireg[j][b];
+                        f32x2 im2[2] = {{iv.x, iv.y}, {iv.z, iv.w}}, ww2[2] = {ws2, ws2};
+                        if (wgt) {
+                            const float4 wv = reinterpret_cast<const float4 *>(wgt + (size_t)b * HW)[g];
+                            ww2[0] = (f32x2){wv.x, wv.y}; ww2[1] = (f32x2){wv.z, wv.w};
+                        }
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            f32x2 model = sed[0][b] * m2[0][p];
+#pragma unroll
+                            for (int k = 1; k < KM; ++k) model += sed[k][b] * m2[k][p];
+                            const f32x2 d = ww2[p] * (model - im2[p]);
+                            loss2 += d * d;
+                            const f32x2 gg = ww2[p] * d;
+#pragma unroll
+                            for (int k = 0; k < KM; ++k) { dsed2[k][b] += gg * m2[k][p]; gm2[k][p] += sed[k][b] * gg; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K && !fixm[k]) {
+                        const f32x2 o0 = m2[k][0] - step_morph * gm2[k][0], o1 = m2[k][1] - step_morph * gm2[k][1];
+                        lds_store4(tiles + k * tile_floats + y * LW + x, make_float4(o0.x, o0.y, o1.x, o1.y));
+                    }
+            }
+        }
+        float part[NP];
+        part[0] = 0.5f * (loss2.x + loss2.y);
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int b = 0; b < BM; ++b) part[1 + k * BM + b] = dsed2[k][b].x + dsed2[k][b].y;
+        wave_sum_lastrow(part);                 // float partials per wave, float64 across the waves
+        if (lane == SC_WAVE - 1) {
+            red[wid][0] = part[0];
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+#pragma unroll
+                for (int b = 0; b < BM; ++b)
+                    if (k < K && b < B) red[wid][1 + k * B + b] = part[1 + k * BM + b];
+        }
+    }
+    __syncthreads();
+    STAMP(3);
+    for (int i = tid; i < 1 + K * B; i += SC_FB2) {
+        double r = 0;
+#pragma unroll
+        for (int w = 0; w < SC_NW2; ++w) r += (double)red[w][i];
+        tot[i] = r;
+    }
+    __syncthreads();
+    for (int i = tid; i < K * B; i += SC_FB2) {
+        const int k = i / B, b = i - k * B;
+        const float curv = sed_s[k * BM + b];
+        const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + k];
+        sed_new[k * BM + b] = fixed ? curv : curv - step_sed * (float)tot[1 + i];
+    }
+    if (tid == 0 && it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = tot[0];
+    __syncthreads();
+    STAMP(4);
+
+    // ---------------- phase 2: constraints, one PAIR of waves (k, k + 4) per component
+    const int k = wid & 3, half = wid >> 2;
+    const bool mine = k < K;
+    const int c = s * K + (mine ? k : 0);
+    Tile t; t.H = H; t.W = W; t.LW = LW; t.m = tiles + (mine ? k : 0) * tile_floats;
+    float *vec = vecs + (mine ? k : 0) * SC_PAIR_VEC_FLOATS;
+    float *zv = vec + 384 + SC_WAVE * half;
+    int cy = 0, cx = 0, stat = 0;
+    int mode = 0;                                   // 0: nothing, 1: k-space, 2: flip (no shift yet)
+    SymWindow sw = {0, 0, 1, 1, true};
+    KsGeom kg = {};
+    float sy = 0.f;
+    bool rank1 = false;
+    if (mine) {
+        cy = a.centers[2 * c]; cx = a.centers[2 * c + 1];
+        wave_max_pixel(t, cy, cx, stat);            // both waves of the pair, identically
+        if (a.symmetric) {
+            double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
+            if (it_new % 5 == 0) {
+                // (the partner recomputes the same values: whatever it read from a.shifts is overwritten)
+                wave_centroid(t, a.centroid_psf, a.centroid_P, cy, cx, dy, dx, stat);
+                if (half == 0 && lane == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
+            }
+            sw = sym_window(H, W, cy, cx);
+            mode = (dy != dy) ? 2 : (sw.centered ? 0 : 1);
+            if (mode == 1) {
+                kg = ks_geom(sw);
+                sy = pair_ks_vectors(kg, dy, dx, vec, half);
+                rank1 = sy != 0.f;
+                if (rank1) pair_ks_colsums(t, sw, kg, zv);
+            }
+        }
+    }
+    STAMP(8);
+    __syncthreads();                                // B1: Hankel vectors complete
+    f32x4 T[4][2];
+    if (mine && mode == 1) {
+        if (rank1) pair_ks_z(kg, vec + 256, zv);
+        pair_ks_gemm1(t, sw, kg, vec, half, T);
+    }
+    __syncthreads();                                // B2: every read of X is done
+    if (mine && mode == 1) pair_ks_gemm2(t, sw, kg, vec, zv, half, T, sy, rank1);
+    if (mine && mode == 2 && half == 0) wave_flip_symmetry<float>(t, sw, false, 1.0f);
+    __syncthreads();                                // B3
+    STAMP(9);
+    if (mine && half == 0) {
+        int lstop = 1 << 30;                        // last sweep level computed (early exit)
+        if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f, &lstop);
+        if (lane == 0) { lstop_s[k] = lstop; a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
+    }
+    __syncthreads();                                // B4
+    STAMP(10);
+    // ---- sparsity, positivity (update.py:71-82, 27-32), normalisation (update.py:62-65),
+    // store, convergence sums: one pass over the LDS tile, float4 groups split between the pair
+    float norm = 0.f;
+    float l0 = a.l0_thresh >= 0.f ? a.l0_thresh * step_morph : -1.f;
+    float l1 = a.l1_thresh >= 0.f ? a.l1_thresh * step_morph : -1.f;
+    auto sparse = [&](float v) {
+        if (l0 >= 0.f && fabsf(v) < l0) v = 0.f;
+        if (l1 >= 0.f) {
+            const float mag = fabsf(v) - l1;
+            v = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
+        }
+        return v;
+    };
+    // lane -> (row, float4 group) walk without divisions: +128 groups per step
+    const int dyq = (2 * SC_WAVE) / gpr, dxq = 2 * SC_WAVE - dyq * gpr;
+    const int g0 = lane + SC_WAVE * half;
+    const int y0 = g0 / gpr, x0 = g0 - y0 * gpr;
+    if (!a.monotonic) {                             // (kernel-uniform branch: barriers inside are safe)
+        float vmax = -INFINITY;
+        bool anynan = false;
+        if (mine) {
+            int y = y0, xq = x0;
+            for (int g = g0; g < ngroups; g += 2 * SC_WAVE) {
+                float *p = t.m + y * LW + (xq << 2);
+                float4 v = lds_load4(p);
+                v.x = sparse(v.x); v.y = sparse(v.y); v.z = sparse(v.z); v.w = sparse(v.w);
+                v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
+                v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+                anynan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+                vmax = fmaxf(fmaxf(vmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                lds_store4(p, v);
+                y += dyq; xq += dxq;
+                if (xq >= gpr) { xq -= gpr; ++y; }
+            }
+            vmax = wave_max(vmax);
+            if (__any(anynan)) vmax = __builtin_nanf("");
+            if (lane == 0) nmax_s[k][half] = vmax;
+        }
+        __syncthreads();
+        if (mine) {
+            const float m0 = nmax_s[k][0], m1 = nmax_s[k][1];
+            norm = (m0 != m0 || m1 != m1) ? __builtin_nanf("") : fmaxf(m0, m1);
+        }
+        l0 = -1.f; l1 = -1.f;                       // applied
+    } else if (mine) {
+        // after the sweep no pixel exceeds the peak pixel (each is capped by a convex
+        // combination of pixels closer to the peak) and the maps above are monotone:
+        // morph.max() is the processed peak value (a NaN elsewhere: see below)
+        norm = sparse(t.m[cy * LW + cx]);
+        if (norm < 0.f) norm = 0.f;
+    }
+    if (mine) {
+        const int lstop = lstop_s[k];
+        const bool cut = lstop < (1 << 30);
+        const bool regular = norm > 0.f && !isinf(norm);             // else: the reference's 0/0, x/inf, NaN results
+        const float rnorm = 1.0f / norm;
+        const float4 *last4 = reinterpret_cast<const float4 *>(min_g + (size_t)k * HW);
+        float4 *out4 = reinterpret_cast<float4 *>(mout_g + (size_t)k * HW);
+        // the previous morphology (buffer c0), all requests in flight together
+        float4 lastv[GPW];
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) {
+            const int g = g0 + j * 2 * SC_WAVE;
+            lastv[j] = g < ngroups ? last4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float d2f = 0.f, n2f = 0.f;                      // <= 32 float terms per lane, then f64 across lanes
+        // CUT: zero beyond the sweep's last level; GEN: thresholds and/or an irregular norm
+        auto final_pass = [&](auto cut_c, auto gen_c) {
+            constexpr bool CUT = decltype(cut_c)::value, GEN = decltype(gen_c)::value;
+            int y = y0, xq = x0;
+#pragma unroll
+            for (int j = 0; j < GPW; ++j) {
+                const int g = g0 + j * 2 * SC_WAVE;
+                if (g < ngroups) {
+                    const float4 v4 = lds_load4(t.m + y * LW + (xq << 2));
+                    const float4 l = lastv[j];
+                    float v[4] = {v4.x, v4.y, v4.z, v4.w}, o[4];
+                    const int ay = y < cy ? cy - y : y - cy;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (GEN) v[e] = sparse(v[e]);
+                        v[e] = v[e] < 0.f ? 0.f : v[e];                       // NaN stays NaN
+                        if (CUT) {
+                            const int x = (xq << 2) + e, ax = x < cx ? cx - x : x - cx;
+                            if (max(ax, ay) + ax + ay > lstop) v[e] = 0.f;
+                        }
+                        if (GEN && !regular) o[e] = v[e] / norm;
+                        else {
+                            // v / norm, correctly rounded (but for rare double roundings):
+                            // one Newton step on v * (1 / norm)
+                            const float q = v[e] * rnorm;
+                            o[e] = fmaf(fmaf(-q, norm, v[e]), rnorm, q);
+                        }
+                    }
+                    out4[g] = make_float4(o[0], o[1], o[2], o[3]);
+                    const float e0 = l.x - o[0], e1 = l.y - o[1], e2 = l.z - o[2], e3 = l.w - o[3];
+                    d2f += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+                    n2f += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                }
+                y += dyq; xq += dxq;
+                if (xq >= gpr) { xq -= gpr; ++y; }
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);    // two groups in flight (VGPRs)
+            }
+        };
+        using std::true_type; using std::false_type;
+        if (regular && l0 < 0.f && l1 < 0.f) {
+            if (cut) final_pass(true_type{}, false_type{}); else final_pass(false_type{}, false_type{});
+        } else {
+            final_pass(true_type{}, true_type{});
+        }
+        const double d2 = wave_sum((double)d2f), n2 = wave_sum((double)n2f);
+        if (lane == 0) { conv_m[k][half][0] = d2; conv_m[k][half][1] = n2; }
+        if (half == 0) {
+            double d2s = 0, n2s = 0;
+            if (lane < B) {
+                float v = sed_new[k * BM + lane];
+                if (v < 0.f) v = 0.f;
+                v = v * norm;
+                sed_out[k * B + lane] = v;
+                const float d = sed_s[k * BM + lane] - v;
+                d2s = (double)(d * d);
+                n2s = (double)(v * v);
+            }
+            d2s = wave_sum(d2s); n2s = wave_sum(n2s);
+            if (lane == 0) { conv_s[k][0] = d2s; conv_s[k][1] = n2s; }
+        }
+    }
+    __syncthreads();                                // B5
+    if (mine && norm == norm) {
+        // a NaN pixel away from the peak (NaN sums with a non-NaN norm): np.max is NaN and the
+        // reference's morph becomes NaN everywhere
+        const double n2 = conv_m[k][0][1] + conv_m[k][1][1];
+        if (n2 != n2) {
+            norm = __builtin_nanf("");
+            float4 *out4 = reinterpret_cast<float4 *>(mout_g + (size_t)k * HW);
+            const float4 nan4 = make_float4(norm, norm, norm, norm);
+            for (int g = g0; g < ngroups; g += 2 * SC_WAVE) out4[g] = nan4;
+            if (half == 0 && lane < B) sed_out[k * B + lane] = norm;
+        }
+    }
+    if (mine && half == 0 && lane == 0) {
+        if (!(norm > 0.f) || isinf(norm)) stat |= SCARLET_STATUS_NONFINITE;
+        if (stat) atomicOr(&a.status[s], stat);
+    }
+    STAMP(5);
+
+    // ---------------- phase 3: Blend._check_convergence + bookkeeping (blend.py:141-184)
+    if (tid == 0) {
+        a.it[s] = it_new;
+        a.cur[s] = 1 - c0;
+        if (it_new > 1) {
+            bool done = true;
+            for (int kk = 0; kk < K; ++kk) {
+                int f = a.flags[s * K + kk];
+                const double d2 = conv_m[kk][0][0] + conv_m[kk][1][0], n2 = conv_m[kk][0][1] + conv_m[kk][1][1];
+                if (n2 == n2 && conv_s[kk][0] <= a.e_rel2 * conv_s[kk][1]) f &= ~SCARLET_FLAG_SED_NOT_CONVERGED;
+                else { f |= SCARLET_FLAG_SED_NOT_CONVERGED; done = false; }
+                if (d2 <= a.e_rel2 * n2) f &= ~SCARLET_FLAG_MORPH_NOT_CONVERGED;
+                else { f |= SCARLET_FLAG_MORPH_NOT_CONVERGED; done = false; }
+                a.flags[s * K + kk] = f;
+            }
+            if (done) a.active[s] = 0;
+        }
+    }
+    STAMP(6);
+#undef STAMP
+}

@@ -15,6 +15,7 @@
 #include "prox_ops.h"
 #include "engine.h"
 #include "fused.h"
+#include "fused2.h"
 #include "psf_path.h"
 
 __constant__ unsigned short sc_nfl_table[SC_NFL_MAX];
@@ -851,6 +852,24 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
         hipLaunchKernelGGL((k_iterate<KM_, BM_>), dim3(b->S), dim3(SC_BLOCK), lds, st, f);             \
         prof_stop(st);                                                                                 \
     } while (0)
+    // K <= 4, B <= 5: eight waves per scene, a pair of waves per component (fused2.h; its 128-VGPR
+    // budget does not hold a sixth band's accumulators)
+    if (b->K <= 4 && b->B <= 5 && !getenv("SCARLET_FUSED_V1")) {
+        const size_t lds2 = sizeof(float) * ((size_t)b->K * b->H * tile_stride(b->W) + (size_t)b->K * SC_PAIR_VEC_FLOATS) +
+                            (getenv("SCARLET_PAD_LDS") ? (size_t)atoi(getenv("SCARLET_PAD_LDS")) : 0);
+#define LAUNCH_ITERATE2(BM_)                                                                           \
+    do {                                                                                               \
+        rc = allow_lds(k_iterate2<4, BM_>, lds2);                                                      \
+        if (rc) return rc;                                                                             \
+        prof_start(4, st);                                                                             \
+        hipLaunchKernelGGL((k_iterate2<4, BM_>), dim3(b->S), dim3(SC_FB2), lds2, st, f);               \
+        prof_stop(st);                                                                                 \
+    } while (0)
+        LAUNCH_ITERATE2(5);
+#undef LAUNCH_ITERATE2
+        HIP_TRY(hipGetLastError());
+        return SCARLET_OK;
+    }
     if (b->K <= 4) { if (b->B <= 6) LAUNCH_ITERATE(4, 6); else LAUNCH_ITERATE(4, SC_BMAX); }
     else           { if (b->B <= 6) LAUNCH_ITERATE(SC_KMAX, 6); else LAUNCH_ITERATE(SC_KMAX, SC_BMAX); }
 #undef LAUNCH_ITERATE

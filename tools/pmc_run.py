@@ -8,7 +8,10 @@ S = int(os.environ.get("PMC_SCENES", "10000"))
 d = synth.make_batch(0, 512)
 reps = (S + 511) // 512
 imgs = np.tile(d["images"], (reps, 1, 1, 1))[:S]; cen = np.tile(d["centers"], (reps, 1, 1))[:S]
-b = BlendBatch(imgs, cen)
+kw = {}
+if os.environ.get('PMC_NOSYM'): kw['symmetric'] = False
+if os.environ.get('PMC_NOMONO'): kw['monotonic'] = False
+b = BlendBatch(imgs, cen, **kw)
 b.init_extended(np.ones(5) * .1)
 b.fit(5, e_rel=0, check_every=0)
 torch.cuda.synchronize()
