@@ -32,6 +32,14 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
                             __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// wave-uniform values that the compiler cannot prove uniform (they come out of LDS / shuffles):
+// moving them to SGPRs turns every branch on them into a scalar branch (no exec masking, no
+// accumulator copies around MFMA chains)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uniform(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 #define SC_DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
 #define SC_DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
 #define SC_DPP_HALF_MIRROR 0x141

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
     __shared__ float sed_s[KM * BM], sed_new[KM * BM];
     __shared__ float step_s[2];
     __shared__ double conv_s[KM][4];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = uniform(tid >> 6);    // wid in an SGPR: scalar branches
     const int c0 = a.cur[s];
     const float *min_g = a.morph[c0] + (size_t)s * K * HW;
     float *mout_g = a.morph[1 - c0] + (size_t)s * K * HW;
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
         int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
         int stat = 0;
         wave_max_pixel(t, cy, cx, stat);
+        cy = uniform(cy); cx = uniform(cx);
         if (a.symmetric) {
             double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
             if (it_new % 5 == 0) {
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
                 if (lane == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
             }
             STAMP(8);
+            cy = uniform(cy); cx = uniform(cx); dy = uniform(dy); dx = uniform(dx);
             const bool none = (dy != dy);
             wave_symmetry(t, cy, cx, none ? SCARLET_SYM_SOFT : SCARLET_SYM_KSPACE, 1.0f, dy, dx, false, 0.f, vec,
                           (a.stamps && wid == 0) ? a.stamps + (size_t)s * 16 + 12 : nullptr);

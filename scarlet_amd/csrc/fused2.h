@@ -91,96 +91,125 @@ __device__ inline void pair_ks_z(const KsGeom &g, const float *cv, float *zv)
     wave_sync();
 }
 
-// GEMM 1: T[:, tc] = Xw . Hankel(bv)[:, tc] for this wave's column tiles tc = half, half + 2
+// GEMM 1: T[:, tc] = Xw . Hankel(bv)[:, tc] for this wave's column tiles tc = half, half + 2.
+// NTR row tiles x NI column tiles are compile-time (the caller switches on the wave-uniform
+// window size): straight-line MFMA chains, no control flow between them.
+template <int NTR, int NI>
+__device__ __forceinline__ void pair_ks_gemm1_impl(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
+                                                   int half, f32x4 (&T)[4][2])
+{
+    const float *bv = vec + 128;
+    const int LW = t.LW, lane = lane_id(), lr = lane & 15, lq = lane >> 4;
+    // rows beyond the window read row h - 1 and columns beyond it column w - 1; both are masked to 0
+    const float *rowp[NTR];
+    bool rowok[NTR];
+#pragma unroll
+    for (int tr = 0; tr < NTR; ++tr) {
+        const int i = (tr << 4) + lr;
+        rowok[tr] = i < g.h;
+        rowp[tr] = t.m + (s.y0 + min(i, g.h - 1)) * LW + s.x0;
+    }
+    const float *bp = bv + (half << 4) + lr + lq;
+    float a[NTR], b[NI], an[NTR], bn[NI];
+    auto fetch = [&](int k0, float (&fa)[NTR], float (&fb)[NI]) {
+        const int k = k0 + lq, kc = min(k, g.w - 1);
+        const bool kok = k < g.w;
+#pragma unroll
+        for (int tr = 0; tr < NTR; ++tr) {
+            const float x = rowp[tr][kc];
+            fa[tr] = (kok && rowok[tr]) ? x : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fb[i] = bp[k0 + (i << 5)];
+    };
+    fetch(0, a, b);
+    // software pipeline: the operands of step k0 + 4 are in flight while step k0 multiplies
+    for (int k0 = 0; k0 < g.wp; k0 += 4) {
+        fetch(min(k0 + 4, g.wp - 4), an, bn);
+#pragma unroll
+        for (int tr = 0; tr < NTR; ++tr)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                T[tr][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tr], b[i], T[tr][i], 0, 0, 0);
+#pragma unroll
+        for (int tr = 0; tr < NTR; ++tr) a[tr] = an[tr];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) b[i] = bn[i];
+    }
+}
+
 __device__ inline void pair_ks_gemm1(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
                                      int half, f32x4 (&T)[4][2])
 {
-    const float *m = t.m, *bv = vec + 128;
-    const int LW = t.LW, lane = lane_id(), lr = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int tr = 0; tr < 4; ++tr)
 #pragma unroll
         for (int i = 0; i < 2; ++i) T[tr][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (half >= g.ntc) return;
-    // software pipeline: operands of step k0 + 4 are in flight while step k0 multiplies
-    float a[4], b[2], an[4], bn[2];
-    auto fetch = [&](int k0, float (&fa)[4], float (&fb)[2]) {
-        const int k = k0 + lq;
-#pragma unroll
-        for (int tr = 0; tr < 4; ++tr) {
-            const int i = (tr << 4) + lr;
-            fa[tr] = (tr < g.ntr && i < g.h && k < g.w) ? m[(s.y0 + i) * LW + s.x0 + k] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int tc = half + 2 * i;
-            fb[i] = tc < g.ntc ? bv[k + (tc << 4) + lr] : 0.f;
-        }
-    };
-    fetch(0, a, b);
-    for (int k0 = 0; k0 < g.wp; k0 += 4) {
-        if (k0 + 4 < g.wp) fetch(k0 + 4, an, bn);
-#pragma unroll
-        for (int tr = 0; tr < 4; ++tr)
-            if (tr < g.ntr) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    if (half + 2 * i < g.ntc)
-                        T[tr][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tr], b[i], T[tr][i], 0, 0, 0);
-            }
-#pragma unroll
-        for (int tr = 0; tr < 4; ++tr) a[tr] = an[tr];
-        b[0] = bn[0]; b[1] = bn[1];
-    }
+    const int ni = half < g.ntc ? (half + 2 < g.ntc ? 2 : 1) : 0;
+    if (ni == 0) return;
+#define SC_G1(NTR_) do { if (ni == 2) pair_ks_gemm1_impl<NTR_, 2>(t, s, g, vec, half, T);          \
+                         else pair_ks_gemm1_impl<NTR_, 1>(t, s, g, vec, half, T); } while (0)
+    switch (g.ntr) { case 1: SC_G1(1); break; case 2: SC_G1(2); break; case 3: SC_G1(3); break; default: SC_G1(4); }
+#undef SC_G1
 }
 
 // GEMM 2 + epilogue in place for this wave's column tiles
-__device__ inline void pair_ks_gemm2(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
-                                     const float *zv, int half, const f32x4 (&T)[4][2], float sy, bool rank1)
+template <int NTR, int NI>
+__device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
+                                                   const float *zv, int half, const f32x4 (&T)[4][2], float sy, bool rank1)
 {
     float *m = t.m;
     const float *av = vec;
     const int LW = t.LW, lane = lane_id(), lr = lane & 15, lq = lane >> 4;
-    if (half >= g.ntc) return;
+    // rank-1 term: row parity of (row - ry) depends on r only (16 tr and 4 lq are even)
+    float syr[4], zc[NI];
 #pragma unroll
-    for (int tr = 0; tr < 4; ++tr) {
-        if (tr >= g.ntr) continue;
-        float areg[4][4];
+    for (int r = 0; r < 4; ++r) syr[r] = rank1 ? (((r - g.ry) & 1) ? -sy : sy) : 0.f;
 #pragma unroll
-        for (int tk = 0; tk < 4; ++tk)
+    for (int i = 0; i < NI; ++i) zc[i] = rank1 ? zv[((half + 2 * i) << 4) + lr] : 0.f;
+#pragma unroll
+    for (int tr = 0; tr < NTR; ++tr) {
+        float areg[NTR][4];
+#pragma unroll
+        for (int tk = 0; tk < NTR; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) areg[tk][r] = av[(tr << 4) + lr + (tk << 4) + 4 * lq + r];
+        f32x4 acc[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tk = 0; tk < NTR; ++tk)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                areg[tk][r] = tk < g.ntr ? av[(tr << 4) + lr + (tk << 4) + 4 * lq + r] : 0.f;
-        f32x4 acc[2];
-        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
 #pragma unroll
-        for (int tk = 0; tk < 4; ++tk) {
-            if (tk >= g.ntr) continue;
+                for (int i = 0; i < NI; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[tk][r], T[tk][i][r], acc[i], 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    if (half + 2 * i < g.ntc)
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[tk][r], T[tk][i][r], acc[i], 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int tc = half + 2 * i;
-            if (tc >= g.ntc) continue;
-            const int jcol = (tc << 4) + lr;
+        for (int i = 0; i < NI; ++i) {
+            const int jcol = ((half + 2 * i) << 4) + lr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = (tr << 4) + lq * 4 + r;
                 if (row < g.h && jcol < g.w) {
                     float *p = &m[(s.y0 + row) * LW + s.x0 + jcol];
                     const float x = *p;
-                    float y2 = acc[i][r];
-                    if (rank1) y2 += (((row - g.ry) & 1) ? -sy : sy) * zv[jcol];
+                    const float y2 = acc[i][r] + syr[r] * zc[i];
                     *p = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
                 }
             }
         }
     }
+}
+
+__device__ inline void pair_ks_gemm2(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
+                                     const float *zv, int half, const f32x4 (&T)[4][2], float sy, bool rank1)
+{
+    const int ni = half < g.ntc ? (half + 2 < g.ntc ? 2 : 1) : 0;
+    if (ni == 0) return;
+#define SC_G2(NTR_) do { if (ni == 2) pair_ks_gemm2_impl<NTR_, 2>(t, s, g, vec, zv, half, T, sy, rank1);   \
+                         else pair_ks_gemm2_impl<NTR_, 1>(t, s, g, vec, zv, half, T, sy, rank1); } while (0)
+    switch (g.ntr) { case 1: SC_G2(1); break; case 2: SC_G2(2); break; case 3: SC_G2(3); break; default: SC_G2(4); }
+#undef SC_G2
 }
 
 template <int KM, int BM>
@@ -206,7 +235,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     __shared__ double conv_s[KM][2], conv_m[KM][2][2];
     __shared__ int lstop_s[KM];
     __shared__ float nmax_s[KM][2];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = uniform(tid >> 6);    // wid in an SGPR: scalar branches
     const int c0 = a.cur[s];
     const float *min_g = a.morph[c0] + (size_t)s * K * HW;
     float *mout_g = a.morph[1 - c0] + (size_t)s * K * HW;
@@ -433,6 +462,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     if (mine) {
         cy = a.centers[2 * c]; cx = a.centers[2 * c + 1];
         wave_max_pixel(t, cy, cx, stat);            // both waves of the pair, identically
+        cy = uniform(cy); cx = uniform(cx);
         if (a.symmetric) {
             double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
             if (it_new % 5 == 0) {
@@ -440,6 +470,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
                 wave_centroid(t, a.centroid_psf, a.centroid_P, cy, cx, dy, dx, stat);
                 if (half == 0 && lane == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
             }
+            cy = uniform(cy); cx = uniform(cx); dy = uniform(dy); dx = uniform(dx);
             sw = sym_window(H, W, cy, cx);
             mode = (dy != dy) ? 2 : (sw.centered ? 0 : 1);
             if (mode == 1) {
@@ -452,12 +483,16 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     }
     STAMP(8);
     __syncthreads();                                // B1: Hankel vectors complete
+    STAMP(12);
     f32x4 T[4][2];
     if (mine && mode == 1) {
         if (rank1) pair_ks_z(kg, vec + 256, zv);
+        STAMP(14);
         pair_ks_gemm1(t, sw, kg, vec, half, T);
+        STAMP(15);
     }
     __syncthreads();                                // B2: every read of X is done
+    STAMP(13);
     if (mine && mode == 1) pair_ks_gemm2(t, sw, kg, vec, zv, half, T, sy, rank1);
     if (mine && mode == 2 && half == 0) wave_flip_symmetry<float>(t, sw, false, 1.0f);
     __syncthreads();                                // B3

@@ -13,6 +13,7 @@ b = BlendBatch(imgs, cen, **kw)
 b.init_extended(np.ones(5) * .1)
 b.fit(3, e_rel=0, check_every=0)
 torch.cuda.synchronize()
+b.workspace.zero_()
 b.fit(1, e_rel=0, check_every=0)
 torch.cuda.synchronize()
 st = b.workspace[:S * 16 * 8].view(torch.int64).view(S, 16).cpu().numpy()
@@ -20,10 +21,17 @@ dt = np.diff(st[:, :7], axis=1)
 if st[:, 10].any():
     print("P2 wave0: pre-sym %d  sym %d  sweep %d  tail %d" % ((st[:, 8] - st[:, 4]).mean(), (st[:, 9] - st[:, 8]).mean(),
           (st[:, 10] - st[:, 9]).mean(), (st[:, 5] - st[:, 10]).mean()))
-if st[:, 11].any():
+if st[:, 12].any():
     ok = st[:, 12] > 0
-    print("sym wave0: vectors %d  rank1 %d  gemm1 %d  gemm2 %d  (n=%d)" % ((st[ok, 12] - st[ok, 8]).mean(), (st[ok, 13] - st[ok, 12]).mean(),
-          (st[ok, 14] - st[ok, 13]).mean(), (st[ok, 9] - st[ok, 14]).mean(), ok.sum()))
-    print("P2 wave0 own tail:", (st[:, 11] - st[:, 10]).mean().round(0))
+    if st[:, 11].any():
+        print("sym wave0: vectors %d  rank1 %d  gemm1 %d  gemm2 %d  (n=%d)" % ((st[ok, 12] - st[ok, 8]).mean(), (st[ok, 13] - st[ok, 12]).mean(),
+              (st[ok, 14] - st[ok, 13]).mean(), (st[ok, 9] - st[ok, 14]).mean(), ok.sum()))
+    else:
+        print("sym (pair kernel): to B1 %d  B1->B2 (rank1 z + gemm1) %d  B2->B3 (gemm2 + epilogue) %d" % ((st[ok, 12] - st[ok, 8]).mean(),
+              (st[ok, 13] - st[ok, 12]).mean(), (st[ok, 9] - st[ok, 13]).mean()))
+        o2 = st[:, 15] > 0
+        print("   wave0: z %d  gemm1 %d  wait-B2 %d  (n=%d)" % ((st[o2, 14] - st[o2, 12]).mean(), (st[o2, 15] - st[o2, 14]).mean(),
+              (st[o2, 13] - st[o2, 15]).mean(), o2.sum()))
+    if st[:, 11].any(): print("P2 wave0 own tail:", (st[:, 11] - st[:, 10]).mean().round(0))
 print("phase cycles mean:", dt.mean(axis=0).round(0), " total", (st[:, 6] - st[:, 0]).mean())
 print("phase cycles p90 :", np.percentile(dt, 90, axis=0).round(0))
