@@ -102,20 +102,19 @@ struct Walker {
     T c4;
 };
 
+// walker of minor index mi (a row for the x-major wedges, a column for the y-major ones)
 template <typename T>
-__device__ __forceinline__ Walker<T> make_walker(bool xmajor, int e, int H, int W, int LW, int cy, int cx,
-                                                 int half, int k2)
+__device__ __forceinline__ Walker<T> walker_at(bool xmajor, int mi, int H, int W, int LW, int cy, int cx, int half)
 {
     Walker<T> w;
     const int cmin = xmajor ? cy : cx, cmaj = xmajor ? cx : cy;
     const int dimmin = xmajor ? H : W, dimmaj = xmajor ? W : H;
     const int strmin = xmajor ? LW : 1, strmaj = xmajor ? 1 : LW;
     const int dir = half ? -1 : 1;
-    const int mi = k2 + ((e + cmin) & 1);                       // minor index active at levels = e (mod 2)
     const int Yb = mi - cmin;
     const int s = Yb > 0 ? -1 : 1;                              // minor step towards the axis
     w.b = Yb < 0 ? -Yb : Yb;
-    w.valid = mi < dimmin;
+    w.valid = (unsigned)mi < (unsigned)dimmin;
     w.ok1 = (unsigned)(mi + s) < (unsigned)dimmin;
     w.ok3 = (unsigned)(mi - s) < (unsigned)dimmin;
     w.amin = xmajor ? max(w.b, 1) : w.b + 1;
@@ -129,46 +128,71 @@ __device__ __forceinline__ Walker<T> make_walker(bool xmajor, int e, int H, int 
     w.c4 = (T)w.b;
     return w;
 }
+// two-trip layout: lane k of a 32-lane half owns minor index 2k + parity
+template <typename T>
+__device__ __forceinline__ Walker<T> make_walker(bool xmajor, int e, int H, int W, int LW, int cy, int cx,
+                                                 int half, int k2)
+{
+    const int cmin = xmajor ? cy : cx;
+    return walker_at<T>(xmajor, k2 + ((e + cmin) & 1), H, W, LW, cy, cx, half);   // active at levels = e (mod 2)
+}
+// Compact layout for the levels l <= SC_COMPACT_LAST: a level-l pixel has b <= l / 3 < 16, so
+// 16 lanes per wedge (two sides of the axis x eight values b = 2 j + parity) cover all four
+// wedges in ONE trip.  (Even, so that the two-trip loop resumes on an odd level.)
+#define SC_COMPACT_LAST 46
+template <typename T>
+__device__ __forceinline__ Walker<T> make_compact_walker(int e, int H, int W, int LW, int cy, int cx, int lane)
+{
+    const int wedge = lane >> 4, side = (lane >> 3) & 1, j = lane & 7;
+    const bool xmajor = wedge < 2;
+    const int b = 2 * j + e;
+    const int mi = (xmajor ? cy : cx) + (side ? -b : b);
+    Walker<T> w = walker_at<T>(xmajor, mi, H, W, LW, cy, cx, wedge & 1);
+    if (side && b == 0) w.valid = false;                        // the axis itself belongs to side 0
+    return w;
+}
 
 template <typename T>
 __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thresh, int *last_level = nullptr)
 {
     const int H = t.H, W = t.W, LW = t.LW;
     T *m = t.m;
-    const int lane = lane_id(), half = lane >> 5, k2 = (lane & 31) << 1;
+    const int lane = lane_id();
     const int mxr = max(cx, W - 1 - cx), myr = max(cy, H - 1 - cy);
     const int Lall = 2 * max(mxr, myr) + min(mxr, myr);
     const T one_minus = (T)1 - thresh;
     const T R2 = (T)0.70710678118654752440;
     const int psafe = min(1, H - 1) * LW + min(1, W - 1);       // interior address for idle lanes
-    // walkers: [trip: 0 = right/left wedges, 1 = down/up wedges][level parity]
-    const Walker<T> wx0 = make_walker<T>(true, 0, H, W, LW, cy, cx, half, k2);
-    const Walker<T> wx1 = make_walker<T>(true, 1, H, W, LW, cy, cx, half, k2);
-    const Walker<T> wy0 = make_walker<T>(false, 0, H, W, LW, cy, cx, half, k2);
-    const Walker<T> wy1 = make_walker<T>(false, 1, H, W, LW, cy, cx, half, k2);
-    struct Px { int p; bool act; T x0, x1, x2, x3, x4, c1, c2, c3, c4; };
-    auto gather = [&](int ell, const Walker<T> &w) {
-        Px q;
+    // One level = prepare (addresses and weights: lane arithmetic only) -> load (five LDS reads)
+    // -> finish (cap, conditional store).  The level's critical path is store -> load -> finish,
+    // so the NEXT level is prepared while this level's reads are in flight.
+    struct Prep { int p; bool act; T c1, c2, c3; };
+    struct Vals { T x0, x1, x2, x3, x4; };
+    auto prepare = [&](int ell, const Walker<T> &w) {
+        Prep q;
         const int a = (ell - w.b) >> 1;
         q.act = w.valid && a >= w.amin && a <= w.lim;
-        q.p = q.act ? w.base + a * w.step : psafe;
+        q.p = q.act ? w.base + __mul24(a, w.step) : psafe;
         q.c1 = (w.ok1 && a + w.b > 1) ? (T)(a + w.b) * R2 : (T)0;
         q.c2 = (T)a;
         q.c3 = (w.ok3 && w.b < a - 1) ? (T)(a - w.b) * R2 : (T)0;
-        q.c4 = w.c4;
-        q.x0 = m[q.p]; q.x2 = m[q.p + w.sa]; q.x1 = m[q.p + w.off1];
-        q.x3 = m[q.p + w.off3]; q.x4 = m[q.p + w.off4];
         return q;
     };
-    auto finish = [&](const Px &q) {
-        const T inv = fast_rcp(q.c1 + q.c2 + q.c3 + q.c4);
+    auto load = [&](const Prep &q, const Walker<T> &w) {
+        Vals v;
+        v.x0 = m[q.p]; v.x2 = m[q.p + w.sa]; v.x1 = m[q.p + w.off1];
+        v.x3 = m[q.p + w.off3]; v.x4 = m[q.p + w.off4];
+        return v;
+    };
+    auto finish = [&](const Prep &q, const Vals &v, const Walker<T> &w) {
+        const T inv = fast_rcp(q.c1 + q.c2 + q.c3 + w.c4);
         // unused neighbours were read from a dummy address: mask them (0 * NaN != 0)
-        const T t1 = q.c1 > 0 ? q.x1 * q.c1 : (T)0, t3 = q.c3 > 0 ? q.x3 * q.c3 : (T)0;
-        const T t4 = q.c4 > 0 ? q.x4 * q.c4 : (T)0;
-        const T cap = ((q.x2 * q.c2 + t1) + (t3 + t4)) * inv * one_minus;
-        const bool lower = q.act && cap < q.x0;
+        const T t1 = q.c1 > 0 ? v.x1 * q.c1 : (T)0, t3 = q.c3 > 0 ? v.x3 * q.c3 : (T)0;
+        const T t4 = w.c4 > 0 ? v.x4 * w.c4 : (T)0;
+        const T cap = ((v.x2 * q.c2 + t1) + (t3 + t4)) * inv * one_minus;
+        const bool lower = q.act && cap < v.x0;
         if (lower) m[q.p] = cap;
-        return q.act && (lower ? cap : q.x0) > (T)0;          // does this pixel end up positive?
+        return q.act && (lower ? cap : v.x0) > (T)0;          // does this pixel end up positive?
     };
     // Early exit (only when the caller applies positivity afterwards, as the source pipeline
     // does, and 0 <= thresh <= 1): every closer neighbour of a level-l pixel lies on levels
@@ -178,27 +202,69 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     // receives the last level that was computed; the caller zeroes everything beyond it.
     const bool early = last_level != nullptr && thresh >= (T)0 && thresh <= (T)1;
     int quiet = 0, done = 1 << 30;               // 1 << 30: swept to the end
-    for (int ell = 1; ell <= Lall; ell += 2) {
-        {   // odd level
-            const Px qa = gather(ell, wx1);
-            const Px qb = gather(ell, wy1);
-            const bool pa = finish(qa);
-            const bool pb = finish(qb);
-            wave_sync();
-            if (early) {
-                quiet = __any(pa || pb) ? 0 : quiet + 1;
-                if (quiet >= 3) { done = ell; break; }
+    int ell = 1;
+    bool stop = false;
+    {   // ---- levels 1 .. 46: one trip per level
+        const Walker<T> c0 = make_compact_walker<T>(0, H, W, LW, cy, cx, lane);
+        const Walker<T> c1 = make_compact_walker<T>(1, H, W, LW, cy, cx, lane);
+        const int Lc = min(Lall, SC_COMPACT_LAST);
+        Prep pa = prepare(1, c1);
+        for (; ell <= Lc; ell += 2) {
+            Prep na;
+            {   // odd level
+                const Vals va = load(pa, c1);
+                na = prepare(ell + 1, c0);
+                const bool fa = finish(pa, va, c1);
+                wave_sync();
+                if (early) {
+                    quiet = __any(fa) ? 0 : quiet + 1;
+                    if (quiet >= 3) { done = ell; stop = true; break; }
+                }
+            }
+            if (ell + 1 <= Lc) {   // even level
+                const Vals va = load(na, c0);
+                pa = prepare(ell + 2, c1);
+                const bool fa = finish(na, va, c0);
+                wave_sync();
+                if (early) {
+                    quiet = __any(fa) ? 0 : quiet + 1;
+                    if (quiet >= 3) { done = ell + 1; stop = true; break; }
+                }
             }
         }
-        if (ell + 1 <= Lall) {   // even level
-            const Px qa = gather(ell + 1, wx0);
-            const Px qb = gather(ell + 1, wy0);
-            const bool pa = finish(qa);
-            const bool pb = finish(qb);
-            wave_sync();
-            if (early) {
-                quiet = __any(pa || pb) ? 0 : quiet + 1;
-                if (quiet >= 3) { done = ell + 1; break; }
+    }
+    if (!stop && ell <= Lall) {
+        // ---- levels 47 ..: two trips per level (right/left wedges, then down/up), one walker
+        // per 32-lane half and level parity.  (ell == 47 here.)
+        const int half = lane >> 5, k2 = (lane & 31) << 1;
+        const Walker<T> wx0 = make_walker<T>(true, 0, H, W, LW, cy, cx, half, k2);
+        const Walker<T> wx1 = make_walker<T>(true, 1, H, W, LW, cy, cx, half, k2);
+        const Walker<T> wy0 = make_walker<T>(false, 0, H, W, LW, cy, cx, half, k2);
+        const Walker<T> wy1 = make_walker<T>(false, 1, H, W, LW, cy, cx, half, k2);
+        Prep pa = prepare(ell, wx1), pb = prepare(ell, wy1);
+        for (; ell <= Lall; ell += 2) {
+            Prep na, nb;
+            {   // odd level
+                const Vals va = load(pa, wx1), vb = load(pb, wy1);
+                na = prepare(ell + 1, wx0); nb = prepare(ell + 1, wy0);     // (no active pixel beyond Lall)
+                const bool fa = finish(pa, va, wx1);
+                const bool fb = finish(pb, vb, wy1);
+                wave_sync();
+                if (early) {
+                    quiet = __any(fa || fb) ? 0 : quiet + 1;
+                    if (quiet >= 3) { done = ell; break; }
+                }
+            }
+            if (ell + 1 <= Lall) {   // even level
+                const Vals va = load(na, wx0), vb = load(nb, wy0);
+                pa = prepare(ell + 2, wx1); pb = prepare(ell + 2, wy1);
+                const bool fa = finish(na, va, wx0);
+                const bool fb = finish(nb, vb, wy0);
+                wave_sync();
+                if (early) {
+                    quiet = __any(fa || fb) ? 0 : quiet + 1;
+                    if (quiet >= 3) { done = ell + 1; break; }
+                }
             }
         }
     }
