@@ -307,6 +307,8 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
                 }
         }
     }
+#pragma unroll
+    for (int j = 1; j < GPT; ++j) load_images(j);       // the tile registers are free now
     __syncthreads();
     STAMP(1);
     // Lipschitz constants (blend.py:205-218): L_sed = lambda_max(S S^T) on lane 0,
@@ -366,8 +368,6 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
             for (int b = 0; b < BM; ++b) dsed2[k][b] = (f32x2){0.f, 0.f};
         f32x2 loss2 = {0.f, 0.f};
         const f32x2 ws2 = {a.weight_scalar, a.weight_scalar};
-#pragma unroll
-        for (int j = 1; j < GPT; ++j) load_images(j);
 #pragma unroll
         for (int j = 0; j < GPT; ++j) {
             const int g = tid + j * SC_FB2;
