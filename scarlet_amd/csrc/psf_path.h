@@ -276,7 +276,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_step_psf(PsfArgs a)
                 const float m = mor[(size_t)k * HW + p];
                 float gm = 0.f;
 #pragma unroll
-                for (int b = 0; b < BM; ++b) gm += sed_s[k * BM + b] * gb[b];
+                for (int b = 0; b < BM; ++b)
+                    if (b < B) gm += sed_s[k * BM + b] * gb[b];      // (entries b >= B of sed_s are never written)
                 const bool fixed = a.fix_morph && a.fix_morph[(size_t)s * K + k];
                 mout[(size_t)k * HW + p] = fixed ? m : m - step_morph * gm;
             }

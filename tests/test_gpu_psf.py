@@ -188,3 +188,32 @@ def test_config3_shape_128_psf_k8_vs_oracle(scarlet):
                     rel_err(b.sed_current[i].cpu().numpy(), np.array([s.sed for s in sc.sources])),
                     rel_err(b.mse(i), sc.mse))
     assert worst < 2e-5, worst
+
+
+def test_config3_batch_equals_single_scene_runs(scarlet):
+    """Scenes are independent: a 12-scene batch of the config-3 shape must reproduce, bit for bit, the
+    twelve one-scene runs (regression: an uninitialised LDS entry read by the PSF step kernel turned
+    random components into NaN in large batches only)."""
+    from scarlet_amd import synth, fft as fftmod
+    B, H, W, K, S = 5, 128, 128, 8, 12
+    obs_psfs = np.array([synth.gaussian_psf((41, 41), 1.2 + 0.15 * b) for b in range(B)])
+    model_psf = synth.gaussian_psf((41, 41), 0.9)
+    diff = np.asarray(fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                        fftmod.Fourier(model_psf[None].astype(np.float32))).image, dtype=np.float32)
+    scale = (model_psf.max() / obs_psfs.max(axis=(1, 2))).astype(np.float32)
+    scenes = [synth.make_scene(306 + i, B=B, H=H, W=W, K=K, psfs=obs_psfs) for i in range(S)]
+    images = np.stack([s["images"] for s in scenes]); centers = np.stack([s["centers"] for s in scenes])
+
+    def run(img, cen):
+        b = scarlet.BlendBatch(img, cen, centroid_weight=model_psf.astype(np.float32))
+        b.set_diff_kernel(diff)
+        b.init_extended(np.ones(B) * 0.1, sed_scale=scale)
+        b.fit(3, e_rel=0)
+        torch.cuda.synchronize()
+        return npy(b.morph_current), npy(b.sed_current), npy(b.status), npy(b.centers)
+
+    m, s, st, c = run(images, centers)
+    assert not st.any() and np.isfinite(m).all() and np.isfinite(s).all()
+    for i in range(S):
+        mi, si, sti, ci = run(images[i:i + 1], centers[i:i + 1])
+        assert_array_equal(m[i], mi[0]); assert_array_equal(s[i], si[0]); assert_array_equal(c[i], ci[0])
