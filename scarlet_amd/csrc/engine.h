@@ -380,6 +380,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
     __shared__ int ctr[2];
     __shared__ double shf[2];
     __shared__ int stat;
+    __shared__ int lastpos;
 
     const int c0 = a.cur[s];
     const int wbuf = a.in_iteration ? 1 - c0 : c0;
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
         symmetry_tile(t, cy, cx, none ? SCARLET_SYM_SOFT : SCARLET_SYM_KSPACE, 1.0f, dy, dx,
                       false, 0.f, scr, av, bv, cv, zv);
     }
-    if (a.monotonic) monotonic_tile<false, float>(t, cy, cx, 0.f);         // source.py:436
+    int lstop = 1 << 30;          // last sweep level computed (early exit); pixels beyond are <= 0 -> 0
+    if (a.monotonic) lstop = monotonic_tile<false, float>(t, cy, cx, 0.f, &lastpos);   // source.py:436
     if (threadIdx.x == 0) { a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
 
     // sparse_l0 / sparse_l1 (update.py:71-82; config 5), positive (update.py:27-32),
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
             const float mag = fabsf(v) - a.l1_thresh * step_morph;
             v = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
         }
-        if (v < 0.f) v = 0.f;
+        if (v < 0.f || sweep_level(y, x, cy, cx) > lstop) v = 0.f;
         t.m[y * t.LW + x] = v;
         anynan |= (v != v);
         vmax = fmaxf(vmax, v);

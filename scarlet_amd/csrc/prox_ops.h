@@ -112,9 +112,25 @@ __device__ inline void centroid_tile(const Tile &t, const double *__restrict__ p
 __device__ __forceinline__ int sc_oy(int i) { return i < 3 ? -1 : (i < 5 ? 0 : 1); }
 __device__ __forceinline__ int sc_ox(int i) { return i < 3 ? i - 1 : (i == 3 ? -1 : (i == 4 ? 1 : i - 6)); }
 
-template <bool NEAREST, typename T>
-__device__ inline void monotonic_tile(const TileT<T> &t, int cy, int cx, T thresh)
+// level of pixel (y, x) for a peak at (cy, cx): the sweep's topological level
+__device__ __forceinline__ int sweep_level(int y, int x, int cy, int cx)
 {
+    const int ay = y < cy ? cy - y : y - cy, ax = x < cx ? cx - x : x - cx;
+    return ay > ax ? 2 * ay + ax : 2 * ax + ay;
+}
+
+// `lastpos` (one int of LDS, or NULL): early exit as in wave_monotonic -- only for callers that
+// apply positivity afterwards, with 0 <= thresh <= 1.  Every thread that leaves a positive
+// value at level l stores l there (all writers of a level store the same value); once three
+// consecutive levels stored nothing, all later pixels end <= 0 and the sweep stops.  Returns
+// the last level swept (1 << 30: all of them); the caller zeroes the pixels beyond it.
+template <bool NEAREST, typename T>
+__device__ inline int monotonic_tile(const TileT<T> &t, int cy, int cx, T thresh, int *lastpos = nullptr)
+{
+    if (lastpos) {
+        if (threadIdx.x == 0) *lastpos = 0;
+        __syncthreads();
+    }
     const int H = t.H, W = t.W, LW = t.LW;
     T *m = t.m;
     const int mxr = max(cx, W - 1 - cx), myr = max(cy, H - 1 - cy);
@@ -164,9 +180,13 @@ __device__ inline void monotonic_tile(const TileT<T> &t, int cy, int cx, T thres
             }
             const T cur = m[py * LW + px];
             if (cap < cur) m[py * LW + px] = cap;
+            if (lastpos && (cap < cur ? cap : cur) > (T)0) *lastpos = ell;
         }
         __syncthreads();
+        // (a thread that already runs level ell + 1 may have stored ell + 1: the decision is the same)
+        if (lastpos && ell - *lastpos >= 3) return ell;
     }
+    return 1 << 30;
 }
 
 // ------------------------------------------------------------------------------------

@@ -271,13 +271,6 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     if (last_level) *last_level = done;
 }
 
-// level of pixel (y, x) for a peak at (cy, cx): the sweep's topological level
-__device__ __forceinline__ int sweep_level(int y, int x, int cy, int cx)
-{
-    const int ay = y < cy ? cy - y : y - cy, ax = x < cx ? cx - x : x - cx;
-    return ay > ax ? 2 * ay + ax : 2 * ax + ay;
-}
-
 // ---------------------------------------------------------------- a16 flip symmetry
 template <typename T>
 __device__ inline void wave_flip_symmetry(const TileT<T> &t, const SymWindow &s, bool sdss, T strength)
