@@ -710,10 +710,22 @@ def fit(scene, max_iter=200, e_rel=1e-2, approximate_L=False):
         L_sed, L_morph = lipschitz(seds, morphs, 1, approximate_L, scene.mse)
         for c, g_s, g_m in zip(scene.sources, gs, gm):
             c.L_sed, c.L_morph = L_sed, L_morph
+            prior = getattr(c, "prior", None)
+            if prior is not None:
+                # Component.backward_prior (component.py:177-187): prior = (grad_func, L_func),
+                # both called on the factors before the step (Prior.compute_grad, component.py:58-67)
+                p_gs, p_gm = prior[0](c.sed, c.morph)
+                p_Ls, p_Lm = prior[1](c.sed, c.morph)
+                if not c.fix_morph:
+                    g_m = g_m + p_gm
+                    c.L_morph = c.L_morph + p_Lm
+                if not c.fix_sed:
+                    g_s = g_s + p_gs
+                    c.L_sed = c.L_sed + p_Ls
             if not c.fix_sed:
-                c.sed = c.sed - (1 / L_sed) * g_s
+                c.sed = c.sed - (1 / c.L_sed) * g_s
             if not c.fix_morph:
-                c.morph = c.morph - (1 / L_morph) * g_m
+                c.morph = c.morph - (1 / c.L_morph) * g_m
         it = scene.it
         for c in scene.sources:
             source_update(c, it)

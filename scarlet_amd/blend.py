@@ -170,16 +170,35 @@ class Blend(ComponentTree):
         b._ensure_mse_capacity(max_iter)
         b.active.fill_(1)
         for _ in range(max_iter):
-            for c in self.components:
-                if c.prior is not None:
-                    raise NotImplementedError("Prior hooks are not supported yet (SURVEY.md 8f rank 3)")
-            _lib.check(_lib.lib.scarlet_backward_step(ctypes.byref(b._c), int(bool(approximate_L)), s()))
             cur = int(b.cur[0].item())
+            # Prior hooks (reference blend.py:86-90, component.py:177-187) run on the factors
+            # BEFORE the step: evaluate them now, fold them into the device step afterwards
+            priors = []
+            for k, c in enumerate(self.components):
+                if c.prior is not None:
+                    self._view_buf = cur
+                    c.prior.compute_grad(c)
+                    priors.append((k, c, c._sed.clone(), c._morph.clone()))
+            _lib.check(_lib.lib.scarlet_backward_step(ctypes.byref(b._c), int(bool(approximate_L)), s()))
             self._view_buf = 1 - cur                     # sources see the stepped factors
             L = b.lipschitz[0].cpu().numpy()
             self.L_sed, self.L_morph = float(L[0]), float(L[1])
             for c in self.components:
                 c.L_sed, c.L_morph = self.L_sed, self.L_morph
+            for k, c, sed0, morph0 in priors:
+                # the device stepped with x - g / L; the likelihood gradient is g = (x - x') L and
+                # the reference's step is x - (g + g_prior) / (L + L_prior)
+                dev = sed0.device
+                as_t = lambda v: v.to(dev) if hasattr(v, "to") else __import__("torch").as_tensor(
+                    np.asarray(v, dtype=np.float32), device=dev)
+                if not c.fix_morph:
+                    g = (morph0 - c._morph) * self.L_morph
+                    c.L_morph = self.L_morph + float(c.prior.L_morph)
+                    c._morph.copy_(morph0 - (g + as_t(c.prior.morph_grad)) / c.L_morph)
+                if not c.fix_sed:
+                    g = (sed0 - c._sed) * self.L_sed
+                    c.L_sed = self.L_sed + float(c.prior.L_sed)
+                    c._sed.copy_(sed0 - (g + as_t(c.prior.sed_grad)) / c.L_sed)
             self._it_in_progress = int(b.it[0].item()) + 1
             self.update()
             del self._it_in_progress

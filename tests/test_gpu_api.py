@@ -279,3 +279,37 @@ def test_blend_fit_matches_reference_and_both_pipelines_agree(scarlet):
     srcs3 = [scarlet.ExtendedSource(frame, tuple(int(v) for v in p), obs, bg) for p in scn["centers"]]
     blend3 = scarlet.Blend(srcs3, obs).fit(200, e_rel=1e-2)
     assert blend3.it == int(g["s0_f32_erel_it"]) and blend3.converged
+
+
+def test_prior_hooks_match_the_oracle(scarlet):
+    """Component.backward_prior (reference component.py:177-187, blend.py:86-98): a prior adds its
+    gradient and its Lipschitz constant to ONE component's step.  Quadratic prior on source 1 of a
+    4-source scene, 8 iterations, against the CPU oracle with the same hook."""
+    from oracle import pgm
+    from scarlet_amd import synth
+    scn = synth.make_scene(3)
+    frame = scarlet.Frame(scn["images"].shape)
+    obs = scarlet.Observation(scn["images"]).match(frame)
+    bg = np.ones(5) * 0.1
+    grad = lambda sed, morph: (0.3 * sed, 2.0 * morph)
+    lip = lambda sed, morph: (0.3, 2.0)
+    srcs = [scarlet.ExtendedSource(frame, tuple(int(v) for v in p), obs, bg,
+                                   **({"prior": scarlet.Prior(grad, lip)} if k == 1 else {}))
+            for k, p in enumerate(scn["centers"])]
+    blend = scarlet.Blend(srcs, obs)
+    assert not blend._builtin_pipeline()
+    sed0 = np.array([npy(c.sed) for c in blend.components]); morph0 = np.array([npy(c.morph) for c in blend.components])
+    cen0 = np.array([c.pixel_center for c in blend.components])
+    sh0 = np.array([[float(v) for v in c.shift] for c in blend.components])   # set by the constructors' update()
+    sc = pgm.scene_from_state(scn["images"], sed0, morph0, cen0, sh0)
+    sc.sources[1].prior = (grad, lip)
+    blend.fit(8, e_rel=0)
+    pgm.fit(sc, 8, e_rel=0)
+    assert rel_err(blend.mse, sc.mse) < 1e-5
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), np.array([s.morph for s in sc.sources])) < 1e-5
+    assert rel_err(np.array([npy(c.sed) for c in blend.components]), np.array([s.sed for s in sc.sources])) < 1e-5
+    assert_array_equal(np.array([c.pixel_center for c in blend.components]), np.array([s.center for s in sc.sources]))
+    # the prior changed the fit of that component
+    plain = pgm.scene_from_state(scn["images"], sed0, morph0, cen0, sh0)
+    pgm.fit(plain, 8, e_rel=0)
+    assert rel_err(plain.sources[1].sed, sc.sources[1].sed) > 1e-3
