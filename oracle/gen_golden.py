@@ -305,10 +305,52 @@ def gen_update(sc):
     save("update", **out)
 
 
+def gen_fit_extras(sc):
+    """MultiComponentSource (source.py:242-295, 495-641) and Prior hooks
+    (component.py:39-67, 177-187), which the reference's own tests do not exercise.  float32 frames."""
+    out = {}
+    bg = np.ones(5) * 0.1
+    # ---- one two-component source + two extended sources, 8 iterations
+    scn = synth.make_scene(5)
+    images = scn["images"]
+    frame = sc.Frame(images.shape, dtype=np.float32)
+    obs = sc.Observation(images).match(frame)
+    cen = [tuple(int(v) for v in p) for p in scn["centers"]]
+    multi = sc.MultiComponentSource(frame, cen[0], obs, bg, flux_percentiles=[30])
+    out["multi_init_sed"] = np.array([c.sed for c in multi.components])
+    out["multi_init_morph"] = np.array([c.morph for c in multi.components])
+    out["multi_init_center"] = np.array(multi.pixel_center).astype(np.int64)
+    others = [sc.ExtendedSource(frame, p, obs, bg) for p in cen[1:3]]
+    blend = sc.Blend([multi] + others, obs)
+    blend.fit(8, e_rel=0)
+    out["multi_sed"] = np.array([c.sed for c in blend.components])
+    out["multi_morph"] = np.array([c.morph for c in blend.components])
+    out["multi_mse"] = np.array(blend.mse)
+    out["multi_center"] = np.array(multi.pixel_center).astype(np.int64)
+    # ---- quadratic prior on source 1 of a 4-source scene, 8 iterations
+    scn = synth.make_scene(3)
+    images = scn["images"]
+    frame = sc.Frame(images.shape, dtype=np.float32)
+    obs = sc.Observation(images).match(frame)
+    prior = sc.Prior(lambda sed, morph: (0.3 * sed, 2.0 * morph), lambda sed, morph: (0.3, 2.0))
+    srcs = [sc.ExtendedSource(frame, tuple(int(v) for v in p), obs, bg, **({"prior": prior} if k == 1 else {}))
+            for k, p in enumerate(scn["centers"])]
+    blend = sc.Blend(srcs, obs)
+    blend.fit(8, e_rel=0)
+    out["prior_sed"] = np.array([c.sed for c in blend.components])
+    out["prior_morph"] = np.array([c.morph for c in blend.components])
+    out["prior_mse"] = np.array(blend.mse)
+    out["prior_center"] = np.array([c.pixel_center for c in blend.components]).astype(np.int64)
+    save("fit_extras", **out)
+
+
 def main():
     sc = load_reference()
     import scarlet.cache
     sc.cache = scarlet.cache
+    if len(sys.argv) > 1 and sys.argv[1] == "extras":
+        gen_fit_extras(sc)
+        return
     gen_fft(sc)
     gen_monotonic(sc)
     gen_measure(sc)
@@ -317,6 +359,7 @@ def main():
     gen_update(sc)
     gen_fit_hsc(sc)
     gen_fit_synth(sc)
+    gen_fit_extras(sc)
 
 
 if __name__ == "__main__":

@@ -727,12 +727,78 @@ def fit(scene, max_iter=200, e_rel=1e-2, approximate_L=False):
             if not c.fix_morph:
                 c.morph = c.morph - (1 / c.L_morph) * g_m
         it = scene.it
-        for c in scene.sources:
-            source_update(c, it)
+        trees = getattr(scene, "trees", None)
+        if trees is not None:              # sources made of several components (MultiSource)
+            for t in trees:
+                multi_source_update(t, it) if isinstance(t, MultiSource) else source_update(t, it)
+        else:
+            for c in scene.sources:
+                source_update(c, it)
         if check_convergence(scene, e_rel):
             break
     return scene
 
+
+
+# --------------------------------------------------------------------------- MultiComponentSource
+def best_fit_seds(morphs, images):
+    """source.get_best_fit_seds (source.py:74-98)."""
+    K = len(morphs)
+    S = morphs.reshape(K, -1)
+    data = images.reshape(images.shape[0], -1)
+    return np.dot(np.linalg.inv(np.dot(S, S.T)), np.dot(S, data.T))
+
+
+def init_multicomponent_source(pixel, images, bg_rms, flux_percentiles=None, obs_psfs=None,
+                               frame_psf=None, thresh=1., symmetric=True, monotonic=True):
+    """source.init_multicomponent_source (source.py:242-295)."""
+    if flux_percentiles is None:
+        flux_percentiles = [25]
+    sed, morph = init_extended_source(pixel, images, bg_rms, obs_psfs, frame_psf, thresh, symmetric, monotonic)
+    K = len(flux_percentiles) + 1
+    morphs = np.zeros((K,) + morph.shape, dtype=morph.dtype)
+    morphs[0] = morph
+    max_flux = morph.max()
+    last_thresh = 0
+    for k, perc in enumerate(np.sort(flux_percentiles), start=1):
+        flux_thresh = perc * max_flux / 100
+        mask_ = morph > flux_thresh
+        morphs[k - 1][mask_] = flux_thresh - last_thresh
+        morphs[k][mask_] = morph[mask_] - flux_thresh
+        last_thresh = flux_thresh
+    for k in range(K):
+        morphs[k] /= morphs[k].max()
+    return best_fit_seds(morphs, images), morphs
+
+
+class MultiSource(object):
+    """MultiComponentSource (source.py:495-641): components share centre and shift."""
+
+    def __init__(self, components, center, symmetric=True, monotonic=True, centroid_weight=None):
+        self.components = components
+        self.center = (int(center[0]), int(center[1]))
+        self.shift = None
+        self.symmetric = symmetric
+        self.monotonic = monotonic
+        self.centroid_weight = default_centroid_weight() if centroid_weight is None else centroid_weight
+
+
+def multi_source_update(ms, it):
+    """MultiComponentSource.update (source.py:605-641).  The components themselves never get a
+    `shift` attribute, so update.symmetric passes shift=None (update.py:187-190)."""
+    _morph = np.sum([c.morph * c.sed.sum() for c in ms.components], axis=0)
+    ms.center = max_pixel(_morph, ms.center)
+    if ms.symmetric and it % 5 == 0:
+        ms.center, ms.shift = psf_weighted_centroid(_morph, ms.centroid_weight, ms.center)
+    for c in ms.components:
+        if ms.symmetric:
+            update_symmetric(c.morph, ms.center, None, algorithm="kspace")
+        if ms.monotonic:
+            update_monotonic(c.morph, ms.center)
+        prox_plus(c.sed)
+        prox_plus(c.morph)
+        normalize(c.sed, c.morph, "morph_max")
+        c.center = ms.center
 
 # --------------------------------------------------------------------------- bbox.py
 def trim_bounds(X, min_value=0):

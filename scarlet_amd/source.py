@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from . import measurement
 from . import update
-from .component import Component
+from .component import Component, ComponentTree
 from .psf import generate_psf_image, gaussian
 
 logger = logging.getLogger("scarlet_amd.source")
@@ -191,3 +191,91 @@ class ExtendedSource(PointSource):
         if self.symmetric:
             self._centroid_weight = _default_centroid_weight(self.frame)
         self.update()
+
+
+def init_multicomponent_source(sky_coord, frame, observation, bg_rms, flux_percentiles=None,
+                               thresh=1., symmetric=True, monotonic=True):
+    """(seds, morphs) of a source split into layered components at the given flux percentiles
+    (reference source.py:242-295).  One-time setup: the base morphology comes from the device
+    initialisation, the layering and the least-squares SEDs are host numpy."""
+    if flux_percentiles is None:
+        flux_percentiles = [25]
+    sed, morph = init_extended_source(sky_coord, frame, observation, bg_rms, thresh, symmetric, monotonic)
+    morph = _host(morph)
+    K = len(flux_percentiles) + 1
+    Ny, Nx = morph.shape
+    morphs = np.zeros((K, Ny, Nx), dtype=morph.dtype)
+    morphs[0, :, :] = morph[:, :]
+    max_flux = morph.max()
+    percentiles_ = np.sort(flux_percentiles)
+    last_thresh = 0
+    for k in range(1, K):
+        perc = percentiles_[k - 1]
+        flux_thresh = perc * max_flux / 100
+        mask_ = morph > flux_thresh
+        morphs[k - 1][mask_] = flux_thresh - last_thresh
+        morphs[k][mask_] = morph[mask_] - flux_thresh
+        last_thresh = flux_thresh
+    for k in range(K):
+        if np.all(morphs[k] <= 0):
+            logger.warning("Zero or negative morphology for component {} at y={}, x={}".format(k, *sky_coord))
+        morphs[k] /= morphs[k].max()
+    seds = get_best_fit_seds(morphs, frame, observation)
+    for k in range(K):
+        if np.any(seds[k] <= 0):
+            msg = "Zero or negative SED {} for component {} at y={}, x={}".format(seds[k], k, *sky_coord)
+            (logger.warning if bool(np.all(_host(sed) <= 0)) else logger.info)(msg)
+    return seds, morphs
+
+
+class RandomSource(Component):
+    """Uniform random morphology, SED random or fitted to an observation (reference source.py:298-327)."""
+
+    def __init__(self, frame, observation=None, **component_kwargs):
+        C, Ny, Nx = frame.shape
+        morph = np.random.rand(Ny, Nx)
+        if observation is None:
+            sed = np.random.rand(C)
+        else:
+            sed = get_best_fit_seds(morph[None], frame, observation)[0]
+        super().__init__(frame, sed, morph, **component_kwargs)
+
+
+class MultiComponentSource(ComponentTree):
+    """Extended source made of layered components that share one centre (reference
+    source.py:495-641).  Its update() measures the centre on the flux-weighted sum of the
+    components and constrains every component around it; inside `Blend.fit` it runs through the
+    Python pipeline (device gradient step, these device operators, device convergence check)."""
+
+    def __init__(self, frame, sky_coord, observation, bg_rms, flux_percentiles=None, thresh=1.,
+                 symmetric=True, monotonic=True, center_step=5, delay_thresh=0, **component_kwargs):
+        self.symmetric = symmetric
+        self.monotonic = monotonic
+        self.pixel_center = frame.get_pixel(sky_coord)
+        self.center_step = center_step
+        self.delay_thresh = delay_thresh
+        seds, morphs = init_multicomponent_source(sky_coord, frame, observation, bg_rms, flux_percentiles,
+                                                  thresh, symmetric, monotonic)
+        components = [Component(frame, seds[k], morphs[k], **component_kwargs) for k in range(len(seds))]
+        super().__init__(components)
+        if self.symmetric:
+            self._centroid_weight = _default_centroid_weight(self.frame)
+        self.update()
+
+    def update(self):
+        it = 0 if self._parent is None else self._parent.it
+        # centre from the flux-weighted mean of all components (source.py:613-617)
+        _morph = sum(c.morph * c.sed.sum() for c in self.components)
+        self.pixel_center = measurement.max_pixel(_morph, self.pixel_center)
+        bbox = self.bboxes["thresh"] if hasattr(self, "bboxes") and "thresh" in self.bboxes else None
+        if self.symmetric and it % 5 == 0:
+            self.pixel_center, self.shift = measurement.psf_weighted_centroid(
+                _morph, self._centroid_weight, self.pixel_center)
+        for c in self.components:
+            if self.symmetric:
+                update.symmetric(c, self.pixel_center, algorithm="kspace", bbox=bbox)
+            if self.monotonic:
+                update.monotonic(c, self.pixel_center, bbox=bbox)
+            update.positive(c)
+            update.normalized(c, type='morph_max')
+        return self

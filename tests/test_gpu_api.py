@@ -309,7 +309,60 @@ def test_prior_hooks_match_the_oracle(scarlet):
     assert rel_err(np.array([npy(c.morph) for c in blend.components]), np.array([s.morph for s in sc.sources])) < 1e-5
     assert rel_err(np.array([npy(c.sed) for c in blend.components]), np.array([s.sed for s in sc.sources])) < 1e-5
     assert_array_equal(np.array([c.pixel_center for c in blend.components]), np.array([s.center for s in sc.sources]))
+    # and against the fixture produced by the reference itself (oracle/gen_golden.py gen_fit_extras)
+    g = load_golden("fit_extras")
+    assert rel_err(blend.mse, g["prior_mse"]) < 1e-5
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["prior_morph"]) < 2e-5
+    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["prior_sed"]) < 2e-5
+    assert_array_equal(np.array([c.pixel_center for c in blend.components]), g["prior_center"])
     # the prior changed the fit of that component
     plain = pgm.scene_from_state(scn["images"], sed0, morph0, cen0, sh0)
     pgm.fit(plain, 8, e_rel=0)
     assert rel_err(plain.sources[1].sed, sc.sources[1].sed) > 1e-3
+
+
+def test_multicomponent_source_matches_the_oracle(scarlet):
+    """MultiComponentSource (reference source.py:242-295, 495-641): layered initialisation, shared
+    centre measured on the flux-weighted sum, per-component constraints.  One two-component source
+    + two extended sources, 8 iterations through the Python pipeline, against the CPU oracle."""
+    from oracle import pgm
+    from scarlet_amd import synth
+    scn = synth.make_scene(5)
+    images = scn["images"]
+    frame = scarlet.Frame(images.shape)
+    obs = scarlet.Observation(images).match(frame)
+    bg = np.ones(5) * 0.1
+    cen = [tuple(int(v) for v in p) for p in scn["centers"]]
+    multi = scarlet.MultiComponentSource(frame, cen[0], obs, bg, flux_percentiles=[30])
+    assert multi.n_components == 2
+    # initialisation against the oracle's restatement
+    oseds, omorphs = pgm.init_multicomponent_source(cen[0], images, bg, [30])
+    oms = pgm.MultiSource([pgm.Source(oseds[k], omorphs[k], cen[0], images.dtype) for k in range(2)], cen[0])
+    pgm.multi_source_update(oms, 0)
+    for k in range(2):
+        assert rel_err(npy(multi.components[k].morph), oms.components[k].morph) < 1e-5
+        assert rel_err(npy(multi.components[k].sed), oms.components[k].sed) < 1e-5
+    assert tuple(multi.pixel_center) == oms.center
+    others = [scarlet.ExtendedSource(frame, p, obs, bg) for p in cen[1:3]]
+    blend = scarlet.Blend([multi] + others, obs)
+    comps = blend.components
+    assert len(comps) == 4 and not blend._builtin_pipeline()
+    osrc = []
+    for s in others:
+        o = pgm.Source(npy(s.sed), npy(s.morph), s.pixel_center, images.dtype,
+                       centroid_weight=pgm.default_centroid_weight())
+        o.shift = tuple(float(v) for v in s.shift)
+        osrc.append(o)
+    sc = pgm.Scene(images, oms.components + osrc)
+    sc.trees = [oms] + osrc
+    blend.fit(8, e_rel=0)
+    pgm.fit(sc, 8, e_rel=0)
+    assert rel_err(blend.mse, sc.mse) < 1e-5
+    assert rel_err(np.array([npy(c.morph) for c in comps]), np.array([s.morph for s in sc.sources])) < 1e-5
+    assert rel_err(np.array([npy(c.sed) for c in comps]), np.array([s.sed for s in sc.sources])) < 1e-5
+    assert tuple(multi.pixel_center) == oms.center
+    g = load_golden("fit_extras")                        # produced by the reference itself
+    assert rel_err(blend.mse, g["multi_mse"]) < 1e-5
+    assert rel_err(np.array([npy(c.morph) for c in comps]), g["multi_morph"]) < 2e-5
+    assert rel_err(np.array([npy(c.sed) for c in comps]), g["multi_sed"]) < 2e-5
+    assert_array_equal(np.array(multi.pixel_center), g["multi_center"])

@@ -397,3 +397,37 @@ def test_fit_synth_ragged_and_approx():
     pgm.fit(scene, 30, e_rel=0, approximate_L=True)
     assert rel_err(np.array(scene.mse), g["s0_f32_approx_mse"]) <= 2e-5
     assert rel_err(np.array([s.morph for s in scene.sources]), g["s0_f32_approx_morph"]) <= 2e-5
+
+
+def test_fit_extras_fixture_multicomponent_and_prior():
+    """SURVEY.md 8f rank 3 rows, pinned on fixtures from the reference (oracle/gen_golden.py
+    gen_fit_extras): MultiComponentSource initialisation + 8 iterations, and a Prior hook."""
+    g = load_golden("fit_extras")
+    bg = np.ones(5) * 0.1
+    # ---- MultiComponentSource + two extended sources
+    scn = synth.make_scene(5)
+    images = scn["images"]
+    cen = [tuple(int(v) for v in p) for p in scn["centers"]]
+    seds, morphs = pgm.init_multicomponent_source(cen[0], images, bg, [30])
+    ms = pgm.MultiSource([pgm.Source(seds[k], morphs[k], cen[0], images.dtype) for k in range(2)], cen[0])
+    pgm.multi_source_update(ms, 0)                       # the constructor's update()
+    assert rel_err(np.array([c.morph for c in ms.components]), g["multi_init_morph"]) < 1e-5
+    assert rel_err(np.array([c.sed for c in ms.components]), g["multi_init_sed"]) < 1e-5
+    assert_array_equal(np.array(ms.center), g["multi_init_center"])
+    others = pgm.make_extended_scene(images, cen[1:3], bg).sources
+    sc = pgm.Scene(images, ms.components + others)
+    sc.trees = [ms] + others
+    pgm.fit(sc, 8, e_rel=0)
+    assert rel_err(sc.mse, g["multi_mse"]) < 1e-5
+    assert rel_err(np.array([c.morph for c in sc.sources]), g["multi_morph"]) < 2e-5
+    assert rel_err(np.array([c.sed for c in sc.sources]), g["multi_sed"]) < 2e-5
+    assert_array_equal(np.array(ms.center), g["multi_center"])
+    # ---- Prior on source 1
+    scn = synth.make_scene(3)
+    sc = pgm.make_extended_scene(scn["images"], scn["centers"], bg)
+    sc.sources[1].prior = (lambda sed, morph: (0.3 * sed, 2.0 * morph), lambda sed, morph: (0.3, 2.0))
+    pgm.fit(sc, 8, e_rel=0)
+    assert rel_err(sc.mse, g["prior_mse"]) < 1e-5
+    assert rel_err(np.array([c.morph for c in sc.sources]), g["prior_morph"]) < 2e-5
+    assert rel_err(np.array([c.sed for c in sc.sources]), g["prior_sed"]) < 2e-5
+    assert_array_equal(np.array([c.center for c in sc.sources]), g["prior_center"])
