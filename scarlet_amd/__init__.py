@@ -21,7 +21,7 @@ from .source import (SourceInitError, get_pixel_sed, get_psf_sed, get_best_fit_s
 from .observation import Frame, Observation
 from .blend import Blend
 from .batch import BlendBatch
-from . import bbox, cache, component, source, observation, blend, batch, synth, distributed
+from . import bbox, cache, component, source, observation, blend, batch, synth, distributed, io
 
 update = _update_module
 __version__ = "0.1.0"

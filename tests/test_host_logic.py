@@ -1,6 +1,7 @@
 """CPU: host-side logic of the product (no device work): boxes, cache, pad/centre layouts,
 PSF profiles, scene sharding arithmetic, synthetic generator determinism.  The expected
 arrays are the golden vectors of the reference's own tests (cited per test)."""
+import os
 import numpy as np
 import pytest
 from numpy.testing import assert_array_equal, assert_almost_equal
@@ -105,3 +106,32 @@ def test_synthetic_scenes_are_deterministic():
     for i in range(4):
         for j in range(i):
             assert max(abs(c[i] - c[j])) >= 4
+
+
+def test_scene_npz_loader(tmp_path):
+    """scarlet_amd.io: the reference's data-file layout (images / psfs / variance / mask / filters /
+    structured catalog) -> batch arrays; files are read without pickle."""
+    from scarlet_amd import io
+    rng = np.random.RandomState(0)
+    cat = np.zeros(3, dtype=[("x", "<f8"), ("y", "<f8")])
+    cat["x"] = [10.4, 20.6, 5.5]; cat["y"] = [7.2, 8.9, 30.49]
+    var = rng.rand(4, 40, 32).astype(np.float32) + .5
+    var[0, 0, 0] = 0
+    mask = np.zeros((4, 40, 32), dtype=np.int32); mask[1, 2, 3] = 8
+    p = tmp_path / "scene.npz"
+    np.savez(p, images=rng.rand(4, 40, 32).astype(np.float32), psfs=rng.rand(4, 9, 9), variance=var, mask=mask,
+             filters=np.array(list("griz")), catalog=cat)
+    s = io.load_scene(str(p))
+    assert s["images"].dtype == np.float32 and s["psfs"].dtype == np.float32 and s["channels"] == list("griz")
+    assert s["centers"].tolist() == [[7, 10], [9, 21], [30, 6]]          # (y, x), round half to even
+    assert s["weights"][0, 0, 0] == 0 and s["weights"][1, 2, 3] == 0
+    np.testing.assert_allclose(s["weights"][2], 1 / var[2])
+    images, centers, weights = io.stack_scenes([s, s])
+    assert images.shape == (2, 4, 40, 32) and centers.shape == (2, 3, 2) and weights.shape == images.shape
+    assert io.group_by_shape([s, s]) == {(4, 40, 32, 3): [0, 1]}
+    s2 = dict(s, images=s["images"][:, :30])
+    with pytest.raises(ValueError):
+        io.stack_scenes([s, s2])
+    # the fixture copied from the reference's hsc_cosmos_35 file (catalog stored as an (K, 2) array)
+    h = io.load_scene(os.path.join(os.path.dirname(__file__), "golden", "hsc_inputs.npz"))
+    assert h["images"].shape == (5, 58, 48) and h["psfs"].shape == (5, 43, 43) and h["centers"].shape == (7, 2)
