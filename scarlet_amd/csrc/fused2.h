@@ -5,13 +5,13 @@
 // to two scenes, each SIMD holds two waves and sits idle ~45 % of the time waiting on LDS /
 // MFMA / HBM latencies (profiles/r01_notes.md).  LDS cannot hold a third scene, so the
 // second lever is used: the same two scenes per CU run as 2 x 8 waves (four per SIMD, 128
-// VGPRs each) and every component is served by a PAIR of waves (wave k and wave k + 4,
-// which share SIMD k):
+// VGPRs each) and every component is served by a PAIR of waves (waves 2k and 2k + 1, on two
+// different SIMDs):
 //
 //   phases 0/1   pixel-parallel over 512 threads (two float4 groups per thread)
 //   k-space symmetry  vectors: 64 entries per wave; T = X B and Y = A T split by column
 //                tiles (wave h owns tiles h, h + 2) -- T never leaves the accumulators
-//   sweep        wave k alone (its partner waits at the barrier and costs no issue slots)
+//   sweep        one wave of the pair (its partner waits at the barrier and costs no issue slots)
 //   tail         float4 groups split between the pair
 //
 // The pair is synchronised with workgroup barriers placed outside all divergent code, so
@@ -446,8 +446,12 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     __syncthreads();
     STAMP(4);
 
-    // ---------------- phase 2: constraints, one PAIR of waves (k, k + 4) per component
-    const int k = wid & 3, half = wid >> 2;
+    // ---------------- phase 2: constraints, one PAIR of waves (2k, 2k + 1) per component.  The two
+    // waves sit on different SIMDs, so the MFMA work of a big window spreads over two matrix
+    // pipes; the wave that also runs the sweep and the bookkeeping (`lead`) alternates so that the
+    // four sweeps of a scene land on four different SIMDs.
+    const int k = wid >> 1, half = wid & 1;
+    const bool lead = half == ((k >> 1) & 1);
     const bool mine = k < K;
     const int c = s * K + (mine ? k : 0);
     Tile t; t.H = H; t.W = W; t.LW = LW; t.m = tiles + (mine ? k : 0) * tile_floats;
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
             if (it_new % 5 == 0) {
                 // (the partner recomputes the same values: whatever it read from a.shifts is overwritten)
                 wave_centroid(t, a.centroid_psf, a.centroid_P, cy, cx, dy, dx, stat);
-                if (half == 0 && lane == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
+                if (lead && lane == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
             }
             cy = uniform(cy); cx = uniform(cx); dy = uniform(dy); dx = uniform(dx);
             sw = sym_window(H, W, cy, cx);
@@ -494,13 +498,30 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     __syncthreads();                                // B2: every read of X is done
     STAMP(13);
     if (mine && mode == 1) pair_ks_gemm2(t, sw, kg, vec, zv, half, T, sy, rank1);
-    if (mine && mode == 2 && half == 0) wave_flip_symmetry<float>(t, sw, false, 1.0f);
+    if (mine && mode == 2 && lead) wave_flip_symmetry<float>(t, sw, false, 1.0f);
     __syncthreads();                                // B3
     STAMP(9);
-    if (mine && half == 0) {
+    // lane -> (row, float4 group) walk of the final pass without divisions: +128 groups per step
+    const int dyq = (2 * SC_WAVE) / gpr, dxq = 2 * SC_WAVE - dyq * gpr;
+    const int g0 = lane + SC_WAVE * half;
+    const int y0 = g0 / gpr, x0 = g0 - y0 * gpr;
+    // the previous morphology (buffer c0) for the convergence sums: requested now, all 16 B/lane
+    // loads in flight together, so that the HBM latency is paid under the sweep
+    float4 lastv[GPW];
+    auto load_last = [&]() {
+        const float4 *last4 = reinterpret_cast<const float4 *>(min_g + (size_t)k * HW);
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) {
+            const int g = g0 + j * 2 * SC_WAVE;
+            lastv[j] = g < ngroups ? last4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (mine && !lead) load_last();                 // the idle wave of the pair: before the barrier
+    if (mine && lead) {
         int lstop = 1 << 30;                        // last sweep level computed (early exit)
         if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f, &lstop);
         if (lane == 0) { lstop_s[k] = lstop; a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
+        load_last();
     }
     __syncthreads();                                // B4
     STAMP(10);
@@ -517,10 +538,6 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         }
         return v;
     };
-    // lane -> (row, float4 group) walk without divisions: +128 groups per step
-    const int dyq = (2 * SC_WAVE) / gpr, dxq = 2 * SC_WAVE - dyq * gpr;
-    const int g0 = lane + SC_WAVE * half;
-    const int y0 = g0 / gpr, x0 = g0 - y0 * gpr;
     if (!a.monotonic) {                             // (kernel-uniform branch: barriers inside are safe)
         float vmax = -INFINITY;
         bool anynan = false;
@@ -560,15 +577,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         const bool cut = lstop < (1 << 30);
         const bool regular = norm > 0.f && !isinf(norm);             // else: the reference's 0/0, x/inf, NaN results
         const float rnorm = 1.0f / norm;
-        const float4 *last4 = reinterpret_cast<const float4 *>(min_g + (size_t)k * HW);
         float4 *out4 = reinterpret_cast<float4 *>(mout_g + (size_t)k * HW);
-        // the previous morphology (buffer c0), all requests in flight together
-        float4 lastv[GPW];
-#pragma unroll
-        for (int j = 0; j < GPW; ++j) {
-            const int g = g0 + j * 2 * SC_WAVE;
-            lastv[j] = g < ngroups ? last4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         float d2f = 0.f, n2f = 0.f;                      // <= 32 float terms per lane, then f64 across lanes
         // CUT: zero beyond the sweep's last level; GEN: thresholds and/or an irregular norm
         auto final_pass = [&](auto cut_c, auto gen_c) {
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         }
         const double d2 = wave_sum((double)d2f), n2 = wave_sum((double)n2f);
         if (lane == 0) { conv_m[k][half][0] = d2; conv_m[k][half][1] = n2; }
-        if (half == 0) {
+        if (lead) {
             double d2s = 0, n2s = 0;
             if (lane < B) {
                 float v = sed_new[k * BM + lane];
@@ -641,10 +650,10 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
             float4 *out4 = reinterpret_cast<float4 *>(mout_g + (size_t)k * HW);
             const float4 nan4 = make_float4(norm, norm, norm, norm);
             for (int g = g0; g < ngroups; g += 2 * SC_WAVE) out4[g] = nan4;
-            if (half == 0 && lane < B) sed_out[k * B + lane] = norm;
+            if (lead && lane < B) sed_out[k * B + lane] = norm;
         }
     }
-    if (mine && half == 0 && lane == 0) {
+    if (mine && lead && lane == 0) {
         if (!(norm > 0.f) || isinf(norm)) stat |= SCARLET_STATUS_NONFINITE;
         if (stat) atomicOr(&a.status[s], stat);
     }
