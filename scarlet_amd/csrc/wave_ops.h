@@ -92,19 +92,27 @@ __device__ inline void wave_centroid(const Tile &t, const double *__restrict__ p
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // <= 1 ulp
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 
-// Per-lane walker: everything that does not change along a walk (one per wedge trip and
-// level parity), so that a level costs ~40 VALU instructions per trip.
+// Per-lane walker: everything that does not change along a walk (one per wedge and level
+// parity).  A walker is used every second level and moves one pixel outwards per use, so the
+// per-level state is a running address and a running major index; validity of the two diagonal
+// neighbours is folded into the constants (fb1 = -inf / fb3 = +inf when the neighbour row or
+// column does not exist: the weight test below then fails by itself).
 template <typename T>
 struct Walker {
-    int base, step, b, amin, lim;      // p = base + a*step ; a = (ell - b) >> 1 in [amin, lim]
+    int step;                          // address step per use (elements)
     int sa, off1, off3, off4;          // neighbour offsets from p (0 when never valid)
-    bool valid, ok1, ok3;
-    T c4;
+    T c4;                              // weight of n4 = b
+    T fb1, fb3;                        // b (or -inf / +inf): n1 weight (a + b) R2 iff a + fb1 >= 2, n3 weight (a - b) R2 iff a - fb3 >= 2
+    T famin, flim;                     // active iff famin <= a <= flim (famin = +inf: never)
+    int base, b;                       // p = base + a * step ; a = (level - b) >> 1
 };
+template <typename T>
+struct WalkState { int p; T fa; };     // address and major index of the NEXT use
 
 // walker of minor index mi (a row for the x-major wedges, a column for the y-major ones)
 template <typename T>
-__device__ __forceinline__ Walker<T> walker_at(bool xmajor, int mi, int H, int W, int LW, int cy, int cx, int half)
+__device__ __forceinline__ Walker<T> walker_at(bool xmajor, int mi, int H, int W, int LW, int cy, int cx, int half,
+                                               bool enabled = true)
 {
     Walker<T> w;
     const int cmin = xmajor ? cy : cx, cmaj = xmajor ? cx : cy;
@@ -114,19 +122,33 @@ __device__ __forceinline__ Walker<T> walker_at(bool xmajor, int mi, int H, int W
     const int Yb = mi - cmin;
     const int s = Yb > 0 ? -1 : 1;                              // minor step towards the axis
     w.b = Yb < 0 ? -Yb : Yb;
-    w.valid = (unsigned)mi < (unsigned)dimmin;
-    w.ok1 = (unsigned)(mi + s) < (unsigned)dimmin;
-    w.ok3 = (unsigned)(mi - s) < (unsigned)dimmin;
-    w.amin = xmajor ? max(w.b, 1) : w.b + 1;
-    w.lim = half ? cmaj : dimmaj - 1 - cmaj;
+    const bool valid = enabled && (unsigned)mi < (unsigned)dimmin;
+    const bool ok1 = (unsigned)(mi + s) < (unsigned)dimmin;
+    const bool ok3 = (unsigned)(mi - s) < (unsigned)dimmin;
+    const int amin = xmajor ? max(w.b, 1) : w.b + 1;
+    const int lim = half ? cmaj : dimmaj - 1 - cmaj;
     w.base = mi * strmin + cmaj * strmaj;
     w.step = dir * strmaj;
     w.sa = -w.step;
-    w.off1 = w.ok1 ? w.sa + s * strmin : 0;
-    w.off3 = w.ok3 ? w.sa - s * strmin : 0;
+    w.off1 = ok1 ? w.sa + s * strmin : 0;
+    w.off3 = ok3 ? w.sa - s * strmin : 0;
     w.off4 = w.b > 0 ? s * strmin : 0;
     w.c4 = (T)w.b;
+    w.fb1 = ok1 ? (T)w.b : -(T)INFINITY;
+    w.fb3 = ok3 ? (T)w.b : (T)INFINITY;
+    w.famin = valid ? (T)amin : (T)INFINITY;
+    w.flim = (T)lim;
     return w;
+}
+// state of walker w for its use at `level` (level = b mod 2)
+template <typename T>
+__device__ __forceinline__ WalkState<T> walk_from(const Walker<T> &w, int level)
+{
+    const int a = (level - w.b) >> 1;
+    WalkState<T> st;
+    st.p = w.base + a * w.step;
+    st.fa = (T)a;
+    return st;
 }
 // two-trip layout: lane k of a 32-lane half owns minor index 2k + parity
 template <typename T>
@@ -147,9 +169,7 @@ __device__ __forceinline__ Walker<T> make_compact_walker(int e, int H, int W, in
     const bool xmajor = wedge < 2;
     const int b = 2 * j + e;
     const int mi = (xmajor ? cy : cx) + (side ? -b : b);
-    Walker<T> w = walker_at<T>(xmajor, mi, H, W, LW, cy, cx, wedge & 1);
-    if (side && b == 0) w.valid = false;                        // the axis itself belongs to side 0
-    return w;
+    return walker_at<T>(xmajor, mi, H, W, LW, cy, cx, wedge & 1, !(side && b == 0));   // the axis belongs to side 0
 }
 
 template <typename T>
@@ -168,14 +188,17 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     // so the NEXT level is prepared while this level's reads are in flight.
     struct Prep { int p; bool act; T c1, c2, c3; };
     struct Vals { T x0, x1, x2, x3, x4; };
-    auto prepare = [&](int ell, const Walker<T> &w) {
+    // weights of this use from the running state, then one step outwards
+    auto prepare = [&](WalkState<T> &st, const Walker<T> &w) {
         Prep q;
-        const int a = (ell - w.b) >> 1;
-        q.act = w.valid && a >= w.amin && a <= w.lim;
-        q.p = q.act ? w.base + __mul24(a, w.step) : psafe;
-        q.c1 = (w.ok1 && a + w.b > 1) ? (T)(a + w.b) * R2 : (T)0;
-        q.c2 = (T)a;
-        q.c3 = (w.ok3 && w.b < a - 1) ? (T)(a - w.b) * R2 : (T)0;
+        const T fa = st.fa;
+        q.act = fa >= w.famin && fa <= w.flim;
+        q.p = q.act ? st.p : psafe;
+        const T t1 = fa + w.fb1, t3 = fa - w.fb3;                 // a + b, a - b (exact small integers)
+        q.c1 = t1 > (T)1.5 ? t1 * R2 : (T)0;
+        q.c2 = fa;
+        q.c3 = t3 > (T)1.5 ? t3 * R2 : (T)0;
+        st.p += w.step; st.fa = fa + (T)1;
         return q;
     };
     auto load = [&](const Prep &q, const Walker<T> &w) {
@@ -207,13 +230,14 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     {   // ---- levels 1 .. 46: one trip per level
         const Walker<T> c0 = make_compact_walker<T>(0, H, W, LW, cy, cx, lane);
         const Walker<T> c1 = make_compact_walker<T>(1, H, W, LW, cy, cx, lane);
+        WalkState<T> s0 = walk_from(c0, 2), s1 = walk_from(c1, 1);
         const int Lc = min(Lall, SC_COMPACT_LAST);
-        Prep pa = prepare(1, c1);
+        Prep pa = prepare(s1, c1);
         for (; ell <= Lc; ell += 2) {
             Prep na;
             {   // odd level
                 const Vals va = load(pa, c1);
-                na = prepare(ell + 1, c0);
+                na = prepare(s0, c0);                           // (no active pixel beyond Lall)
                 const bool fa = finish(pa, va, c1);
                 wave_sync();
                 if (early) {
@@ -223,7 +247,7 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
             }
             if (ell + 1 <= Lc) {   // even level
                 const Vals va = load(na, c0);
-                pa = prepare(ell + 2, c1);
+                pa = prepare(s1, c1);
                 const bool fa = finish(na, va, c0);
                 wave_sync();
                 if (early) {
@@ -241,12 +265,14 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         const Walker<T> wx1 = make_walker<T>(true, 1, H, W, LW, cy, cx, half, k2);
         const Walker<T> wy0 = make_walker<T>(false, 0, H, W, LW, cy, cx, half, k2);
         const Walker<T> wy1 = make_walker<T>(false, 1, H, W, LW, cy, cx, half, k2);
-        Prep pa = prepare(ell, wx1), pb = prepare(ell, wy1);
+        WalkState<T> sx0 = walk_from(wx0, ell + 1), sx1 = walk_from(wx1, ell);
+        WalkState<T> sy0 = walk_from(wy0, ell + 1), sy1 = walk_from(wy1, ell);
+        Prep pa = prepare(sx1, wx1), pb = prepare(sy1, wy1);
         for (; ell <= Lall; ell += 2) {
             Prep na, nb;
             {   // odd level
                 const Vals va = load(pa, wx1), vb = load(pb, wy1);
-                na = prepare(ell + 1, wx0); nb = prepare(ell + 1, wy0);     // (no active pixel beyond Lall)
+                na = prepare(sx0, wx0); nb = prepare(sy0, wy0);
                 const bool fa = finish(pa, va, wx1);
                 const bool fb = finish(pb, vb, wy1);
                 wave_sync();
@@ -257,7 +283,7 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
             }
             if (ell + 1 <= Lall) {   // even level
                 const Vals va = load(na, wx0), vb = load(nb, wy0);
-                pa = prepare(ell + 2, wx1); pb = prepare(ell + 2, wy1);
+                pa = prepare(sx1, wx1); pb = prepare(sy1, wy1);
                 const bool fa = finish(na, va, wx0);
                 const bool fb = finish(nb, vb, wy0);
                 wave_sync();
