@@ -43,27 +43,37 @@ __device__ __forceinline__ KsGeom ks_geom(const SymWindow &s)
 __device__ inline float pair_ks_vectors(const KsGeom &g, double dy, double dx, float *vec, int half)
 {
     float *av = vec, *bv = vec + 128, *cv = vec + 256;
-    const double s2y = sinpi(2.0 * dy), s2x = sinpi(2.0 * dx), c2x = cospi(2.0 * dx);
+    // float64 only where the cancellation lives (the arguments and sin/cos); the final quotients
+    // are float32: the kernel entries feed a float32 GEMM
+    double s2x, c2x;
+    const double s2y = sinpi(2.0 * dy);
+    sincospi(2.0 * dx, &s2x, &c2x);
+    const double iFy = 1.0 / g.Fy, iFx = 1.0 / g.Fx;
     const int q = lane_id() + SC_WAVE * half;
     float va = 0.f, vb = 0.f, vc = 0.f;
     if (q <= 2 * (g.h - 1)) {
         const int n = q - 2 * g.ry;
         const double tt = (double)n - 2.0 * dy;
-        const double sn = sinpi(tt / g.Fy), cs = cospi(tt / g.Fy);
+        double sn, cs;
+        sincospi(tt * iFy, &sn, &cs);
         const double spt = (n & 1) ? s2y : -s2y;
-        va = (float)(sn == 0.0 ? 1.0 : ((g.Fy & 1) ? spt / (g.Fy * sn) : spt * cs / (g.Fy * sn)));
+        va = sn == 0.0 ? 1.f : (float)((g.Fy & 1) ? spt : spt * cs) / (float)(g.Fy * sn);
     }
     if (q <= 2 * (g.w - 1)) {
         const int n = q - 2 * g.rx;
         const double tt = (double)n - 2.0 * dx;
-        const double sn = sinpi(tt / g.Fx), cs = cospi(tt / g.Fx);
+        double sn, cs;
+        sincospi(tt * iFx, &sn, &cs);
         const double spt = (n & 1) ? s2x : -s2x;
         const double cpt = (n & 1) ? -c2x : c2x;
         if (sn == 0.0) { vb = 1.f; vc = 0.f; }
-        else { vb = (float)(spt * cs / (g.Fx * sn)); vc = (float)(-(1.0 - cpt) * cs / (g.Fx * sn)); }
+        else {
+            const float r = 1.0f / (float)(g.Fx * sn);
+            vb = (float)(spt * cs) * r; vc = (float)(-(1.0 - cpt) * cs) * r;
+        }
     }
     av[q] = va; bv[q] = vb; cv[q] = vc;
-    return (g.Fy & 1) ? 0.f : (float)(s2y / g.Fy);
+    return (g.Fy & 1) ? 0.f : (float)(s2y * iFy);
 }
 
 // rank-1 term, part 1 (tile reads only): zv[j] = sum_i (-1)^(i-ry) X[i][j]
