@@ -27,14 +27,25 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- k-space symmetry, split over a pair of waves (see wave_kspace_symmetry for the maths)
 struct KsGeom { int h, w, ry, rx, ntr, ntc, wp, Fy, Fx; };
-__device__ __forceinline__ KsGeom ks_geom(const SymWindow &s)
+// FFT lengths of a window of half-size r (h = 2 r + 1): fl[0][r] = next_fast_len(2 h + 10) and
+// fl[1][r] = the first EVEN fast length from there (fft.py:95-115 via operator.py:253-288),
+// tabulated in LDS at kernel start so that the constraint phase does not wait on constant loads
+__device__ __forceinline__ void ks_fill_lengths(unsigned short (*fl)[32], int tid)
+{
+    if (tid < 32) {
+        const int F = dev_next_fast_len(2 * (2 * tid + 1) + 10);
+        int Fe = F;
+        while (Fe & 1) Fe = dev_next_fast_len(Fe + 1);
+        fl[0][tid] = (unsigned short)F; fl[1][tid] = (unsigned short)Fe;
+    }
+}
+__device__ __forceinline__ KsGeom ks_geom(const SymWindow &s, const unsigned short (*fl)[32])
 {
     KsGeom g;
     g.h = s.h; g.w = s.w; g.ry = s.h / 2; g.rx = s.w / 2;
     g.ntr = round16(s.h) >> 4; g.wp = round16(s.w); g.ntc = g.wp >> 4;
-    g.Fy = dev_next_fast_len(2 * s.h + 10);
-    g.Fx = dev_next_fast_len(2 * s.w + 10);
-    while (g.Fx & 1) g.Fx = dev_next_fast_len(g.Fx + 1);
+    g.Fy = uniform((int)fl[0][g.ry]);
+    g.Fx = uniform((int)fl[1][g.rx]);
     return g;
 }
 
@@ -245,6 +256,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     __shared__ double conv_s[KM][2], conv_m[KM][2][2];
     __shared__ int lstop_s[KM];
     __shared__ float nmax_s[KM][2];
+    __shared__ unsigned short fl_s[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wid = uniform(tid >> 6);    // wid in an SGPR: scalar branches
     const int c0 = a.cur[s];
     const float *min_g = a.morph[c0] + (size_t)s * K * HW;
@@ -280,6 +292,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     };
     load_images(0);
     for (int i = tid; i < K * B; i += SC_FB2) sed_s[(i / B) * BM + (i % B)] = sed_in[i];
+    ks_fill_lengths(fl_s, tid);
     const bool small_side = (K <= B);          // nonzero spectrum of A^T A == that of A A^T
     __syncthreads();                           // sed_s visible
     {
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
             sw = sym_window(H, W, cy, cx);
             mode = (dy != dy) ? 2 : (sw.centered ? 0 : 1);
             if (mode == 1) {
-                kg = ks_geom(sw);
+                kg = ks_geom(sw, fl_s);
                 sy = pair_ks_vectors(kg, dy, dx, vec, half);
                 rank1 = sy != 0.f;
                 if (rank1) pair_ks_colsums(t, sw, kg, zv);

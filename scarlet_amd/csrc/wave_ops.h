@@ -23,12 +23,23 @@ __device__ __forceinline__ void wave_sync()
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (SC_WAVE - 1); }
 
 // ---------------------------------------------------------------- a8 max_pixel
-// np.argmax order: larger value wins, NaN beats everything, ties -> smaller index.
-__device__ __forceinline__ bool argmax_better(float va, int ia, float vb, int ib)
+// np.argmax order: larger value wins, NaN beats everything, ties -> smaller index.  Each of
+// the 25 window lanes builds one 64-bit key whose unsigned order is exactly that order
+// (monotone map of the float bits in the high word, 31 - rank in the low word); the maximum
+// over lanes 0..31 takes four DPP steps inside the 16-lane rows and two v_readlane.
+__device__ __forceinline__ unsigned argmax_key_hi(float v)
 {
-    const bool na = va != va, nb = vb != vb;
-    if (na || nb) return (na && nb) ? ia < ib : na;
-    return va > vb || (va == vb && ia < ib);
+    unsigned u = __float_as_uint(v);
+    if (u == 0x80000000u) u = 0;                                  // -0 == +0 for argmax
+    return v != v ? 0xFFFFFFFFu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+}
+template <int CTRL>
+__device__ __forceinline__ void key_max_step(unsigned &hi, unsigned &lo)
+{
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);
+    const bool take = h2 > hi || (h2 == hi && l2 > lo);
+    hi = take ? h2 : hi; lo = take ? l2 : lo;
 }
 __device__ inline void wave_max_pixel(const Tile &t, int &cy, int &cx, int &status_bits)
 {
@@ -37,14 +48,17 @@ __device__ inline void wave_max_pixel(const Tile &t, int &cy, int &cx, int &stat
     const int wy = lane / 5, wx = lane - wy * 5;
     const int y = cy - 2 + wy, x = cx - 2 + wx;
     const bool in = lane < 25 && y < t.H && x < t.W;
-    float v = in ? t.m[y * t.LW + x] : -INFINITY;
-    int idx = in ? lane : 1 << 20;                     // row-major rank inside the window
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float v2 = __shfl_xor(v, o, SC_WAVE);
-        const int i2 = __shfl_xor(idx, o, SC_WAVE);
-        if (argmax_better(v2, i2, v, idx)) { v = v2; idx = i2; }
-    }
+    // lanes outside the window: key 0 (below every real key, whose low word is >= 7)
+    unsigned hi = 0, lo = 0;
+    if (in) { hi = argmax_key_hi(t.m[y * t.LW + x]); lo = 31u - (unsigned)lane; }   // row-major rank = lane
+    key_max_step<SC_DPP_XOR1>(hi, lo);
+    key_max_step<SC_DPP_XOR2>(hi, lo);
+    key_max_step<SC_DPP_HALF_MIRROR>(hi, lo);
+    key_max_step<SC_DPP_MIRROR>(hi, lo);
+    const unsigned h0 = __builtin_amdgcn_readlane((int)hi, 0), l0 = __builtin_amdgcn_readlane((int)lo, 0);
+    const unsigned h1 = __builtin_amdgcn_readlane((int)hi, 16), l1 = __builtin_amdgcn_readlane((int)lo, 16);
+    const unsigned best = (h1 > h0 || (h1 == h0 && l1 > l0)) ? l1 : l0;
+    const int idx = 31 - (int)best;
     cy = cy - 2 + idx / 5;
     cx = cx - 2 + idx % 5;
 }
