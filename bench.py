@@ -130,8 +130,11 @@ def main():
     from scarlet_amd import _lib, distributed
     from scarlet_amd.batch import BlendBatch
     _lib.require_gpu()
-    torch.cuda.set_device(local if world > 1 else 0)
-    distributed.init_from_env("nccl" if world > 1 else None)
+    # SCARLET_BENCH_REHEARSE=1: all ranks share GPU 0 and talk over gloo -- a single-GPU rehearsal of
+    # the N > 1 control flow (the real N > 1 runs use one GPU per rank and RCCL)
+    rehearse = bool(os.environ.get("SCARLET_BENCH_REHEARSE"))
+    torch.cuda.set_device(local if world > 1 and not rehearse else 0)
+    distributed.init_from_env(("gloo" if rehearse else "nccl") if world > 1 else None)
 
     batch = BlendBatch(images, centers, mse_capacity=args.steps + args.warmup + 1,
                        symmetric=not args.no_symmetric, monotonic=not args.no_monotonic)

@@ -88,6 +88,8 @@ def gather_scenes(tensors, n_scenes, dst=0):
     out = []
     for t in tensors:
         t = t.contiguous()
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            t = t.cpu()                    # gloo moves host memory only (CPU tests, single-GPU rehearsal)
         if rank == dst:
             parts = []
             for r in range(world):
