@@ -184,7 +184,7 @@ def main():
                 pm = json.load(open(f))
             except Exception:
                 continue
-            if pm.get("kernel", "").startswith(KERNEL_NAMES[dom]) and pm.get("scenes_per_launch") == S:
+            if KERNEL_NAMES[dom] in pm.get("kernel", "") and pm.get("scenes_per_launch") == S:
                 traffic, traffic_src = pm["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
                 break
     out = {
