@@ -1,0 +1,307 @@
+// bigk.h -- the gradient step of Blend.fit for MANY components per scene (8 < K <= 32).
+//
+// The register-tiled kernels of engine.h keep sed[K][B], d loss/d sed[K][B] and the K (K+1)/2
+// Gram accumulators per thread, which stops at K = 8.  Crowded scenes (BASELINE config 5: 30
+// overlapping sources) run the same mathematics in passes over component chunks of eight:
+//
+//   k_bigk_resid      grid (T, S)        model, residual, loss; G_b = w^2 (model_b - image_b)
+//                                        written once to a scratch plane set [S][B][HW]   [a1-a5]
+//   k_bigk_gram       grid (T, pairs, S) 8 x 8 block of the morphology Gram S S^T per
+//                                        chunk pair                                        [a6]
+//   k_bigk_lipschitz  grid (S)           lambda_max(S S^T) by repeated squaring + Rayleigh
+//                                        quotient on one wave, lambda_max(A^T A) by Jacobi [a6]
+//   k_bigk_step       grid (T, chunks, S) d loss/d sed partials and the morphology step    [a5, a7]
+//   k_bigk_sed        grid (S)           SED step                                          [a7]
+//
+// Partial sums use the layout of engine.h (`partials[S][T][P]`, P = 1 + K B + K (K+1) / 2), so
+// the constraint and convergence kernels that follow are the same as for small K.
+#pragma once
+#include "common.h"
+#include "engine.h"
+
+#define SC_KBIG 32
+#define SC_CHUNK 8
+
+// ---- pass 1: model, residual, loss
+__global__ __launch_bounds__(SC_BLOCK) void k_bigk_resid(GradArgs a, float *resid)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.HW;
+    __shared__ float sed_s[SC_KBIG * SC_BMAX];
+    __shared__ double red[SC_NWAVES];
+    const int c0 = a.cur[s];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
+        sed_s[(i / B) * SC_BMAX + (i % B)] = a.sed[c0][(size_t)s * K * B + i];
+    __syncthreads();
+    const float *img = a.images + (size_t)s * B * HW;
+    const float *wgt = a.weights ? a.weights + (size_t)s * B * HW : nullptr;
+    const float *mor = a.morph[c0] + (size_t)s * K * HW;
+    float *G = resid + (size_t)s * B * HW;
+    double loss = 0;
+    const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
+        float model[SC_BMAX];
+#pragma unroll
+        for (int b = 0; b < SC_BMAX; ++b) model[b] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float m = mor[(size_t)k * HW + p];
+#pragma unroll
+            for (int b = 0; b < SC_BMAX; ++b)
+                if (b < B) model[b] += sed_s[k * SC_BMAX + b] * m;
+        }
+#pragma unroll
+        for (int b = 0; b < SC_BMAX; ++b)
+            if (b < B) {
+                const float w = wgt ? wgt[(size_t)b * HW + p] : a.weight_scalar;
+                const float d = w * (model[b] - img[(size_t)b * HW + p]);
+                loss += (double)d * (double)d;
+                G[(size_t)b * HW + p] = w * d;
+            }
+    }
+    loss = block_sum(0.5 * loss, red);
+    if (threadIdx.x == 0) a.partials[((size_t)s * a.T + tile) * n_partials(K, B)] = loss;
+}
+
+// sum of 64 per-thread values over the workgroup; result[i] valid in threads i < 64
+__device__ __forceinline__ double block_sum64(float (&acc)[64], float (*red)[64])
+{
+    wave_sum_lastrow(acc);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == SC_WAVE - 1) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) red[wid][i] = acc[i];
+    }
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int w = 0; w < SC_NWAVES; ++w) r += (double)red[w][threadIdx.x];
+    }
+    return r;
+}
+
+// ---- pass 2: Gram blocks.  blockIdx.y enumerates chunk pairs (c1 <= c2).
+__global__ __launch_bounds__(SC_BLOCK) void k_bigk_gram(GradArgs a)
+{
+    const int s = blockIdx.z, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.HW;
+    const int nch = (K + SC_CHUNK - 1) / SC_CHUNK;
+    int c1 = 0, rem = blockIdx.y;
+    while (rem >= nch - c1) { rem -= nch - c1; ++c1; }
+    const int c2 = c1 + rem;
+    __shared__ float red[SC_NWAVES][64];
+    const float *mor = a.morph[a.cur[s]] + (size_t)s * K * HW;
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
+        float m1[SC_CHUNK], m2[SC_CHUNK];
+#pragma unroll
+        for (int i = 0; i < SC_CHUNK; ++i) {
+            const int k = c1 * SC_CHUNK + i, k2 = c2 * SC_CHUNK + i;
+            m1[i] = k < K ? mor[(size_t)k * HW + p] : 0.f;
+            m2[i] = k2 < K ? mor[(size_t)k2 * HW + p] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < SC_CHUNK; ++i)
+#pragma unroll
+            for (int j = 0; j < SC_CHUNK; ++j) acc[i * SC_CHUNK + j] += m1[i] * m2[j];
+    }
+    const double r = block_sum64(acc, red);
+    if (threadIdx.x < 64) {
+        const int k = c1 * SC_CHUNK + (threadIdx.x >> 3), k2 = c2 * SC_CHUNK + (threadIdx.x & 7);
+        if (k < K && k2 < K && k <= k2) {
+            const int go = k * K - (k * (k - 1)) / 2 + (k2 - k);        // packed upper triangle
+            a.partials[((size_t)s * a.T + tile) * n_partials(K, B) + 1 + K * B + go] = r;
+        }
+    }
+}
+
+// ---- pass 3: Lipschitz constants, one wave per scene (blend.py:186-223)
+// lambda_max of the PSD Gram matrix G (n <= 32): M = G / tr G is squared SC_SQUARINGS times
+// (renormalised by its trace each time), which leaves u1 u1^T up to terms (lambda_i /
+// lambda_1)^(2^SC_SQUARINGS); the Rayleigh quotient of its heaviest column with the ORIGINAL G
+// then misses lambda_1 by at most n / (e 2^(SC_SQUARINGS + 1)) relative (< 1e-8), whatever the
+// spectral gaps.  Each lane owns a 4 x 4 block of the 32 x 32 product.
+#define SC_SQUARINGS 30
+__global__ __launch_bounds__(SC_WAVE) void k_bigk_lipschitz(GradArgs a)
+{
+    const int s = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, P = n_partials(K, B);
+    constexpr int LD = SC_KBIG + 1;
+    __shared__ double Gm[SC_KBIG][LD], M0[SC_KBIG][LD], M1[SC_KBIG][LD];
+    __shared__ double ata[SC_BMAX * SC_BMAX];
+    __shared__ float sed_s[SC_KBIG * SC_BMAX];
+    const int lane = threadIdx.x;
+    const int c0 = a.cur[s];
+    for (int i = lane; i < K * B; i += SC_WAVE)
+        sed_s[(i / B) * SC_BMAX + (i % B)] = a.sed[c0][(size_t)s * K * B + i];
+    for (int i = lane; i < SC_KBIG * SC_KBIG; i += SC_WAVE) {
+        const int k = i / SC_KBIG, k2 = i - k * SC_KBIG;
+        double r = 0;
+        if (k < K && k2 < K) {
+            const int lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
+            const int go = lo * K - (lo * (lo - 1)) / 2 + (hi - lo);
+            for (int t = 0; t < a.T; ++t) r += a.partials[((size_t)s * a.T + t) * P + 1 + K * B + go];
+        }
+        Gm[k][k2] = r;
+    }
+    double loss = 0;
+    for (int t = 0; t < a.T; ++t) loss += a.partials[((size_t)s * a.T + t) * P];
+    __syncthreads();
+    double trace = 0;
+    if (lane < SC_KBIG) trace = Gm[lane][lane];
+    trace = wave_sum(trace);
+    const int it_new = a.it[s] + 1;
+    double L_sed, L_morph;
+    if (a.approximate_L) {
+        double LS = 0;
+        for (int i = lane; i < K * B; i += SC_WAVE) { const float v = sed_s[(i / B) * SC_BMAX + (i % B)]; LS += (double)v * v; }
+        LS = wave_sum(LS);
+        double LA = trace;
+        if (it_new > 1 && loss > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { LA *= 2; LS *= 2; }
+        L_sed = LA; L_morph = LS;
+    } else {
+        // ---- lambda_max(S S^T)
+        const double inv = 1.0 / trace;
+        for (int i = lane; i < SC_KBIG * SC_KBIG; i += SC_WAVE) M0[i / SC_KBIG][i % SC_KBIG] = Gm[i / SC_KBIG][i % SC_KBIG] * inv;
+        __syncthreads();
+        const int bi = (lane >> 3) << 2, bj = (lane & 7) << 2;
+        double (*src)[LD] = M0, (*dst)[LD] = M1;
+        for (int q = 0; q < SC_SQUARINGS; ++q) {
+            double acc[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+            for (int k = 0; k < SC_KBIG; ++k) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { av[r] = src[bi + r][k]; bv[r] = src[k][bj + r]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[r][c] += av[r] * bv[c];
+            }
+            double tr = 0;
+            if (bi == bj) tr = (acc[0][0] + acc[1][1]) + (acc[2][2] + acc[3][3]);
+            tr = wave_sum(tr);
+            const double sc = 1.0 / tr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dst[bi + r][bj + c] = acc[r][c] * sc;
+            __syncthreads();
+            double (*tmp)[LD] = src; src = dst; dst = tmp;
+        }
+        // heaviest column of the (rank-one) power, Rayleigh quotient with G
+        double best = lane < SC_KBIG ? src[lane][lane] : -1.0;
+        int bidx = lane;
+        for (int o = 32; o > 0; o >>= 1) {
+            const double b2 = __shfl_xor(best, o, SC_WAVE);
+            const int i2 = __shfl_xor(bidx, o, SC_WAVE);
+            if (b2 > best || (b2 == best && i2 < bidx)) { best = b2; bidx = i2; }
+        }
+        double v = lane < SC_KBIG ? src[lane][bidx] : 0.0, gv = 0;
+        if (lane < SC_KBIG) dst[0][lane] = v;
+        __syncthreads();
+        if (lane < SC_KBIG)
+            for (int j = 0; j < SC_KBIG; ++j) gv += Gm[lane][j] * dst[0][j];
+        const double num = wave_sum(v * gv), den = wave_sum(v * v);
+        L_sed = num / den;
+        // ---- lambda_max(A^T A): the smaller of the two Gram matrices of the SED matrix (<= 8 x 8)
+        const int n = K < B ? K : B;
+        for (int i = lane; i < n * n; i += SC_WAVE) {
+            const int x = i / n, y = i - x * n;
+            double r = 0;
+            if (K < B) for (int b = 0; b < B; ++b) r += (double)sed_s[x * SC_BMAX + b] * sed_s[y * SC_BMAX + b];
+            else       for (int k = 0; k < K; ++k) r += (double)sed_s[k * SC_BMAX + x] * sed_s[k * SC_BMAX + y];
+            ata[x * n + y] = r;
+        }
+        __syncthreads();
+        L_morph = 0;
+        if (lane == 0) L_morph = jacobi_lambda_max(ata, n, n);
+        L_morph = __shfl(L_morph, 0, SC_WAVE);
+    }
+    if (lane == 0) {
+        if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
+        a.lipschitz[2 * s] = L_sed;
+        a.lipschitz[2 * s + 1] = L_morph;
+    }
+}
+
+// ---- pass 4: d loss / d sed partials and the morphology step for one chunk of components
+__global__ __launch_bounds__(SC_BLOCK) void k_bigk_step(GradArgs a, const float *resid)
+{
+    const int s = blockIdx.z, tile = blockIdx.x, ch = blockIdx.y;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.HW;
+    __shared__ float sed_s[SC_CHUNK * SC_BMAX];
+    __shared__ float red[SC_NWAVES][64];
+    const int c0 = a.cur[s];
+    if (threadIdx.x < SC_CHUNK * SC_BMAX) {
+        const int k = ch * SC_CHUNK + (threadIdx.x >> 3), b = threadIdx.x & 7;
+        sed_s[threadIdx.x] = (k < K && b < B) ? a.sed[c0][((size_t)s * K + k) * B + b] : 0.f;
+    }
+    __syncthreads();
+    const float step_morph = 1.0f / (float)a.lipschitz[2 * s + 1];
+    const float *mor = a.morph[c0] + (size_t)s * K * HW;
+    float *mout = a.morph[1 - c0] + (size_t)s * K * HW;
+    const float *G = resid + (size_t)s * B * HW;
+    bool fixm[SC_CHUNK];
+#pragma unroll
+    for (int i = 0; i < SC_CHUNK; ++i) {
+        const int k = ch * SC_CHUNK + i;
+        fixm[i] = k < K && a.fix_morph && a.fix_morph[(size_t)s * K + k];
+    }
+    float acc[64];                          // dsed[i][b], i = component of the chunk
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
+        float gb[SC_BMAX];
+#pragma unroll
+        for (int b = 0; b < SC_BMAX; ++b) gb[b] = b < B ? G[(size_t)b * HW + p] : 0.f;
+#pragma unroll
+        for (int i = 0; i < SC_CHUNK; ++i) {
+            const int k = ch * SC_CHUNK + i;
+            if (k < K) {
+                const float m = mor[(size_t)k * HW + p];
+                float gm = 0.f;
+#pragma unroll
+                for (int b = 0; b < SC_BMAX; ++b) {
+                    acc[i * SC_BMAX + b] += gb[b] * m;
+                    gm += sed_s[i * SC_BMAX + b] * gb[b];
+                }
+                mout[(size_t)k * HW + p] = fixm[i] ? m : m - step_morph * gm;
+            }
+        }
+    }
+    const double r = block_sum64(acc, red);
+    if (threadIdx.x < 64) {
+        const int k = ch * SC_CHUNK + (threadIdx.x >> 3), b = threadIdx.x & 7;
+        if (k < K && b < B) a.partials[((size_t)s * a.T + tile) * n_partials(K, B) + 1 + k * B + b] = r;
+    }
+}
+
+// ---- pass 5: SED step (blend.py:91-93)
+__global__ __launch_bounds__(SC_BLOCK) void k_bigk_sed(GradArgs a)
+{
+    const int s = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, P = n_partials(K, B);
+    const int c0 = a.cur[s];
+    const float step_sed = 1.0f / (float)a.lipschitz[2 * s];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK) {
+        double g = 0;
+        for (int t = 0; t < a.T; ++t) g += a.partials[((size_t)s * a.T + t) * P + 1 + i];
+        const float cur = a.sed[c0][(size_t)s * K * B + i];
+        const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + i / B];
+        a.sed[1 - c0][(size_t)s * K * B + i] = fixed ? cur : cur - step_sed * (float)g;
+    }
+}

@@ -16,6 +16,7 @@
 #include "engine.h"
 #include "fused.h"
 #include "fused2.h"
+#include "bigk.h"
 #include "psf_path.h"
 
 __constant__ unsigned short sc_nfl_table[SC_NFL_MAX];
@@ -531,8 +532,10 @@ static int check_batch(const scarlet_batch *b)
 {
     if (!b) return set_err(SCARLET_E_ARG, "null batch");
     if (b->S <= 0 || b->K <= 0 || b->B <= 0 || b->H <= 0 || b->W <= 0) return set_err(SCARLET_E_ARG, "bad batch shape");
-    if (b->K > SC_KMAX || b->B > SC_BMAX)
-        return set_err(SCARLET_E_NOTIMPL, "K > 8 or B > 8 not supported by this build of the gradient kernels");
+    if (b->K > SC_KBIG || b->B > SC_BMAX)
+        return set_err(SCARLET_E_NOTIMPL, "K > 32 or B > 8 not supported by this build of the gradient kernels");
+    if (b->K > SC_KMAX && b->diff_kernel)
+        return set_err(SCARLET_E_NOTIMPL, "K > 8 with a PSF difference kernel is not supported yet");
     if (b->W > 256) return set_err(SCARLET_E_TOO_LARGE, "W > 256 unsupported");
     if (!b->images || !b->sed[0] || !b->sed[1] || !b->morph[0] || !b->morph[1] || !b->cur || !b->centers ||
         !b->shifts || !b->flags || !b->lipschitz || !b->mse || !b->it || !b->active || !b->status || !b->workspace)
@@ -561,7 +564,9 @@ static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 static int64_t base_workspace_bytes(const scarlet_batch *b)
 {
     const int64_t P = n_partials(b->K, b->B);
-    return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4) + 256);
+    // K > 8 (bigk.h): one scratch plane set [S][B][HW] for G = w^2 (model - image)
+    const int64_t resid = b->K > SC_KMAX ? align256(sizeof(float) * (int64_t)b->S * b->B * b->H * b->W) : 0;
+    return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4)) + resid + 256;
 }
 struct PsfLayout { int64_t loss, real, spec, khat, total; };
 static PsfLayout psf_layout(const scarlet_batch *b)
@@ -588,6 +593,13 @@ static double *ws_partials(const scarlet_batch *b) { return (double *)b->workspa
 static double *ws_conv(const scarlet_batch *b)
 {
     return (double *)b->workspace + (size_t)b->S * n_tiles(b) * n_partials(b->K, b->B);
+}
+
+static float *ws_resid(const scarlet_batch *b)
+{
+    const int64_t P = n_partials(b->K, b->B);
+    return (float *)((char *)b->workspace +
+                     align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4)));
 }
 
 static GradArgs grad_args(const scarlet_batch *b, int approximate_L)
@@ -750,6 +762,21 @@ extern "C" int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *
     GradArgs a = grad_args(b, approximate_L);
     dim3 grid(a.T, a.S);
     hipStream_t st = (hipStream_t)stream;
+    if (b->K > SC_KMAX) {
+        // many components per scene: passes over chunks of eight (bigk.h)
+        const int nch = (b->K + SC_CHUNK - 1) / SC_CHUNK;
+        float *resid = ws_resid(b);
+        prof_start(0, st);
+        hipLaunchKernelGGL(k_bigk_resid, grid, dim3(SC_BLOCK), 0, st, a, resid);
+        hipLaunchKernelGGL(k_bigk_gram, dim3(a.T, nch * (nch + 1) / 2, a.S), dim3(SC_BLOCK), 0, st, a);
+        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_WAVE), 0, st, a);
+        prof_stop(st); prof_start(1, st);
+        hipLaunchKernelGGL(k_bigk_step, dim3(a.T, nch, a.S), dim3(SC_BLOCK), 0, st, a, (const float *)resid);
+        hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
+        prof_stop(st);
+        HIP_TRY(hipGetLastError());
+        return SCARLET_OK;
+    }
     if (b->K <= 4) {
         prof_start(0, st);
         hipLaunchKernelGGL((k_grad<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
@@ -821,7 +848,7 @@ static size_t fused_lds_bytes(const scarlet_batch *b)
 }
 static bool fused_ok(const scarlet_batch *b, int approximate_L)
 {
-    if (approximate_L || b->diff_kernel || getenv("SCARLET_NO_FUSED")) return false;
+    if (approximate_L || b->diff_kernel || b->K > SC_KMAX || getenv("SCARLET_NO_FUSED")) return false;
     if (b->H > 64 || b->W > 64 || (b->W & 3) || b->H < 3 || b->W < 3) return false;
     return fused_lds_bytes(b) <= LDS_LIMIT - 4096;
 }

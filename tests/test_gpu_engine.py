@@ -146,6 +146,9 @@ def test_batch_independence_and_determinism(BB):
     (7, 7, 32, 32, "k_iterate<8,8>"),
     (5, 3, 96, 80, "general path, workgroup-level constraints (H > 64)"),
     (4, 5, 50, 50, "general path (W % 4 != 0)"),
+    (6, 12, 64, 64, "bigk.h: K > 8 in chunks of eight, wave-level constraints"),
+    (6, 30, 64, 64, "bigk.h: BASELINE config 5's 30 sources and 6 bands on a 64 x 64 frame"),
+    (3, 9, 96, 72, "bigk.h + workgroup-level constraints (H > 64)"),
 ])
 def test_other_shapes_vs_oracle(BB, B, K, H, W, path):
     """Every kernel variant behind scarlet_fit (the dispatch on K, B, H, W is in launch_fused /
