@@ -362,18 +362,34 @@ struct UpdateArgs {
     const double *centroid_psf; int centroid_P;
     double *conv;                     // [S][K][4]: d2_sed, n2_sed, d2_morph, n2_morph
     int force_it0;                    // 1: constructor call (it = 0, ignore `active`)
+    float *gscratch;                  // GT kernels: [S*K][round16(H) * scratch_stride(round16(W))] (T = X B)
 };
 
+// GT = false: the morphology tile and the GEMM scratch live in LDS (tiles up to ~128 x 128).
+// GT = true : frames whose tile does not fit (up to 256 x 256, BASELINE config 5): the same
+//             operators run IN PLACE on the morphology plane in HBM / L2 with the scratch in a
+//             global workspace; only the Hankel vectors are in LDS.  Threads of the workgroup
+//             exchange pixels through global memory across __syncthreads(), exactly as they do
+//             through LDS in the other variant.
+template <bool GT>
 __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
 {
     extern __shared__ __align__(16) float lds[];
     const int c = blockIdx.x, s = c / a.K;
     if (!a.force_it0 && !a.active[s]) return;
     const int H = a.H, W = a.W, HW = H * W, B = a.B;
-    Tile t; t.H = H; t.W = W; t.LW = tile_stride(W); t.m = lds;
-    float *scr = lds + H * t.LW;
     const int hp = round16(H), wp = round16(W);
-    float *av = scr + hp * scratch_stride(wp);
+    Tile t; t.H = H; t.W = W;
+    float *scr, *av;
+    if (GT) {
+        t.LW = W; t.m = nullptr;                    // set below: the plane itself
+        scr = a.gscratch + (size_t)c * hp * scratch_stride(wp);
+        av = lds;
+    } else {
+        t.LW = tile_stride(W); t.m = lds;
+        scr = lds + H * t.LW;
+        av = scr + hp * scratch_stride(wp);
+    }
     float *bv = av + 2 * hp, *cv = bv + 2 * wp, *zv = cv + 2 * wp;
     __shared__ double red[SC_NWAVES];
     __shared__ float redf[SC_NWAVES];
@@ -385,10 +401,12 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
     const int c0 = a.cur[s];
     const int wbuf = a.in_iteration ? 1 - c0 : c0;
     float *gm = a.morph[wbuf] + (size_t)c * HW;
-    for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
-        const int y = i / W, x = i - y * W;
-        t.m[y * t.LW + x] = gm[i];
-    }
+    if (GT) t.m = gm;
+    else
+        for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
+            const int y = i / W, x = i - y * W;
+            t.m[y * t.LW + x] = gm[i];
+        }
     if (threadIdx.x == 0) stat = 0;
     __syncthreads();
     const int it = a.force_it0 ? 0 : a.it[s] + (a.in_iteration ? 1 : 0);   // len(mse)

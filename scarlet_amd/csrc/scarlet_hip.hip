@@ -561,12 +561,19 @@ static PsfGeom psf_geom(int H, int W, int Py, int Px)
     return g;
 }
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+// frames whose tile does not fit LDS: per-component GEMM scratch of the k-space symmetry in HBM
+static int64_t gscratch_bytes(const scarlet_batch *b)
+{
+    if ((b->H <= 64 && b->W <= 64) || update_lds_bytes(b->H, b->W) <= LDS_LIMIT) return 0;
+    return align256(sizeof(float) * (int64_t)b->S * b->K * round16(b->H) * scratch_stride(round16(b->W)));
+}
 static int64_t base_workspace_bytes(const scarlet_batch *b)
 {
     const int64_t P = n_partials(b->K, b->B);
     // K > 8 (bigk.h): one scratch plane set [S][B][HW] for G = w^2 (model - image)
     const int64_t resid = b->K > SC_KMAX ? align256(sizeof(float) * (int64_t)b->S * b->B * b->H * b->W) : 0;
-    return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4)) + resid + 256;
+    return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4)) + resid +
+           gscratch_bytes(b) + 256;
 }
 struct PsfLayout { int64_t loss, real, spec, khat, total; };
 static PsfLayout psf_layout(const scarlet_batch *b)
@@ -600,6 +607,12 @@ static float *ws_resid(const scarlet_batch *b)
     const int64_t P = n_partials(b->K, b->B);
     return (float *)((char *)b->workspace +
                      align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4)));
+}
+
+static float *ws_gscratch(const scarlet_batch *b)
+{
+    const int64_t resid = b->K > SC_KMAX ? align256(sizeof(float) * (int64_t)b->S * b->B * b->H * b->W) : 0;
+    return (float *)((char *)ws_resid(b) + resid);
 }
 
 static GradArgs grad_args(const scarlet_batch *b, int approximate_L)
@@ -806,6 +819,7 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
     u.status = b->status; u.symmetric = b->symmetric; u.monotonic = b->monotonic;
     u.l0_thresh = b->l0_thresh; u.l1_thresh = b->l1_thresh;
     u.centroid_psf = b->centroid_psf; u.centroid_P = b->centroid_P; u.conv = ws_conv(b); u.force_it0 = force_it0;
+    u.gscratch = nullptr;
     if (b->H <= 64 && b->W <= 64 && !getenv("SCARLET_FORCE_BLOCK_UPDATE")) {
         // one wave per component, four components per workgroup (wave_ops.h)
         const size_t lds = sizeof(float) * SC_NWAVES * ((size_t)b->H * tile_stride(b->W) + SC_WAVE_VEC_FLOATS);
@@ -814,11 +828,17 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
         const int n = b->S * b->K;
         hipLaunchKernelGGL(k_source_update_w, dim3((n + SC_NWAVES - 1) / SC_NWAVES), dim3(SC_BLOCK), lds,
                            (hipStream_t)stream, u);
-    } else {
+    } else if (update_lds_bytes(b->H, b->W) <= LDS_LIMIT) {
         const size_t lds = update_lds_bytes(b->H, b->W);
-        rc = allow_lds(k_source_update, lds);
+        rc = allow_lds(k_source_update<false>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_source_update, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
+        hipLaunchKernelGGL(k_source_update<false>, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
+    } else {
+        // frames beyond the LDS tile (up to 256 x 256): operators in place on the plane in HBM / L2
+        if (b->H > 256 || b->W > 256) return set_err(SCARLET_E_TOO_LARGE, "frames larger than 256 x 256 are not supported");
+        u.gscratch = ws_gscratch(b);
+        const size_t lds = sizeof(float) * (2 * round16(b->H) + 5 * round16(b->W));      // av, bv, cv, zv
+        hipLaunchKernelGGL(k_source_update<true>, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
     }
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;

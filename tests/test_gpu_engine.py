@@ -173,3 +173,37 @@ def test_other_shapes_vs_oracle(BB, B, K, H, W, path):
                     rel_err(b.sed_current[i].cpu().numpy(), np.array([s.sed for s in sc.sources])),
                     rel_err(b.mse(i), sc.mse))
     assert worst < TOL, (path, worst)
+
+
+@pytest.mark.parametrize("B,K,H,W,l0", [
+    (3, 3, 160, 144, None),
+    (6, 5, 256, 256, 0.05),
+])
+def test_large_frames_vs_oracle(BB, B, K, H, W, l0):
+    """Frames whose morphology tile does not fit LDS (BASELINE config 5 is 256 x 256 with L0
+    sparsity): the constraint operators run in place on the planes in HBM (k_source_update<true>).
+    The initial state comes from the CPU oracle (the device initialisation keeps a float64 tile in
+    LDS and stops at ~140 x 140); 4 iterations, 2 scenes, against the oracle."""
+    import copy
+    from oracle import pgm
+    from scarlet_amd import synth
+    S, iters = 2, 4
+    scenes = [synth.make_scene(700 + i, B=B, H=H, W=W, K=K) for i in range(S)]
+    init = [pgm.make_extended_scene(s["images"], s["centers"], np.ones(B) * 0.1, l0_thresh=l0) for s in scenes]
+    kw = {} if l0 is None else dict(l0_thresh=l0)
+    b = BB(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]), **kw)
+    b.set_state(np.array([[c.sed for c in sc.sources] for sc in init]),
+                np.array([[c.morph for c in sc.sources] for sc in init]),
+                centers=np.array([[c.center for c in sc.sources] for sc in init]),
+                shifts=np.array([[c.shift for c in sc.sources] for sc in init]))
+    b.fit(iters, e_rel=0)
+    torch.cuda.synchronize()
+    assert int(b.status.abs().sum().item()) == 0
+    worst = 0
+    for i, sc in enumerate(init):
+        pgm.fit(sc, iters, e_rel=0)
+        np.testing.assert_array_equal(b.centers[i].cpu().numpy(), np.array([s.center for s in sc.sources]))
+        worst = max(worst, rel_err(b.morph_current[i].cpu().numpy(), np.array([s.morph for s in sc.sources])),
+                    rel_err(b.sed_current[i].cpu().numpy(), np.array([s.sed for s in sc.sources])),
+                    rel_err(b.mse(i), sc.mse))
+    assert worst < TOL, worst
