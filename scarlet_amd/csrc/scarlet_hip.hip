@@ -987,11 +987,14 @@ struct InitArgs {
     double thresh;
 };
 
-__global__ __launch_bounds__(SC_BLOCK) void k_init_extended(InitArgs a)
+// GT: frames whose float64 tile does not fit LDS work on a tile in a temporary HBM buffer
+template <bool GT>
+__global__ __launch_bounds__(SC_BLOCK) void k_init_extended(InitArgs a, double *gtile)
 {
     extern __shared__ __align__(16) double ldsd[];
     const int c = blockIdx.x, s = c / a.K, H = a.H, W = a.W, HW = H * W, B = a.B;
-    TileT<double> t; t.H = H; t.W = W; t.LW = W + 1; t.m = ldsd;
+    TileT<double> t; t.H = H; t.W = W; t.LW = W + 1;
+    t.m = GT ? gtile + (size_t)c * H * (W + 1) : ldsd;
     __shared__ double red[SC_NWAVES];
     __shared__ float sed_s[SC_BMAX];
     const int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
@@ -1067,9 +1070,20 @@ extern "C" int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host,
             return set_err(SCARLET_E_ARG, "bg_rms must be greater than zero in all channels");
     }
     const size_t lds = sizeof(double) * (size_t)b->H * (b->W + 1);
-    rc = allow_lds(k_init_extended, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_init_extended, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, a);
+    if (lds <= LDS_LIMIT) {
+        rc = allow_lds(k_init_extended<false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_init_extended<false>, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, a,
+                           (double *)nullptr);
+    } else {
+        if (b->H > 256 || b->W > 256) return set_err(SCARLET_E_TOO_LARGE, "frames larger than 256 x 256 are not supported");
+        double *gtile = nullptr;                       // one-time setup: a temporary float64 tile per component
+        HIP_TRY(hipMalloc(&gtile, lds * (size_t)b->S * b->K));
+        hipLaunchKernelGGL(k_init_extended<true>, dim3(b->S * b->K), dim3(SC_BLOCK), 0, (hipStream_t)stream, a, gtile);
+        const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(gtile);
+        HIP_TRY(e1); HIP_TRY(e2);
+    }
     HIP_TRY(hipGetLastError());
     return run_update ? launch_update(b, 0, 1, stream) : SCARLET_OK;   // constructor's self.update()
 }

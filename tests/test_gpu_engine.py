@@ -207,3 +207,33 @@ def test_large_frames_vs_oracle(BB, B, K, H, W, l0):
                     rel_err(b.sed_current[i].cpu().numpy(), np.array([s.sed for s in sc.sources])),
                     rel_err(b.mse(i), sc.mse))
     assert worst < TOL, worst
+
+
+def test_config5_shape_30_sources_256_l0(BB):
+    """BASELINE config 5 at one scene: 6 bands, 256 x 256, 30 overlapping sources (>= 3 px apart),
+    symmetry + monotonicity + L0.  Device initialisation (float64 tile in HBM), then 3 iterations
+    through bigk.h + k_source_update<true>, against the CPU oracle from the same initial state."""
+    from oracle import pgm
+    from scarlet_amd import synth
+    B, K, H, W, l0 = 6, 30, 256, 256, 0.05
+    scn = synth.make_scene(5000, B=B, H=H, W=W, K=K, min_sep=3)
+    b = BB(scn["images"][None], scn["centers"][None], l0_thresh=l0)
+    b.init_extended(np.ones(B) * 0.1)
+    assert int(b.status.abs().sum().item()) == 0
+    sed0 = b.sed_current.cpu().numpy()[0]; morph0 = b.morph_current.cpu().numpy()[0]
+    cen0 = b.centers.cpu().numpy()[0]; sh0 = b.shifts.cpu().numpy()[0]
+    # the device initialisation against the oracle's
+    ref = pgm.make_extended_scene(scn["images"], scn["centers"], np.ones(B) * 0.1, l0_thresh=l0)
+    assert rel_err(morph0, np.array([s.morph for s in ref.sources])) < TOL
+    assert rel_err(sed0, np.array([s.sed for s in ref.sources])) < TOL
+    np.testing.assert_array_equal(cen0, np.array([s.center for s in ref.sources]))
+    iters = 3
+    b.fit(iters, e_rel=0)
+    torch.cuda.synchronize()
+    assert int(b.status.abs().sum().item()) == 0
+    sc = pgm.scene_from_state(scn["images"], sed0, morph0, cen0, sh0, l0_thresh=l0)
+    pgm.fit(sc, iters, e_rel=0)
+    np.testing.assert_array_equal(b.centers[0].cpu().numpy(), np.array([s.center for s in sc.sources]))
+    assert rel_err(b.morph_current[0].cpu().numpy(), np.array([s.morph for s in sc.sources])) < TOL
+    assert rel_err(b.sed_current[0].cpu().numpy(), np.array([s.sed for s in sc.sources])) < TOL
+    assert rel_err(b.mse(0), sc.mse) < TOL
