@@ -97,25 +97,30 @@ struct OpArgs {
     const double *psf; int P;
 };
 
-__global__ __launch_bounds__(SC_BLOCK) void k_operator(OpArgs a)
+// GT: arrays whose tile does not fit LDS (up to 256 x 256) are processed in place in HBM, the GEMM
+// scratch of the k-space symmetry in `gscratch` (see k_source_update<true> in engine.h)
+template <bool GT>
+__global__ __launch_bounds__(SC_BLOCK) void k_operator(OpArgs a, float *gscratch)
 {
     extern __shared__ __align__(16) float lds[];
     const int c = blockIdx.x, H = a.H, W = a.W, HW = H * W;
-    Tile t; t.H = H; t.W = W; t.LW = tile_stride(W); t.m = lds;
-    float *scr = lds + H * t.LW;
     const int hp = round16(H), wp = round16(W);
-    float *av = scr + hp * scratch_stride(wp);
+    float *g = a.x + (size_t)c * HW;
+    Tile t; t.H = H; t.W = W;
+    float *scr, *av;
+    if (GT) { t.LW = W; t.m = g; scr = gscratch + (size_t)c * hp * scratch_stride(wp); av = lds; }
+    else    { t.LW = tile_stride(W); t.m = lds; scr = lds + H * t.LW; av = scr + hp * scratch_stride(wp); }
     float *bv = av + 2 * hp, *cv = bv + 2 * wp, *zv = cv + 2 * wp;
     __shared__ double red[SC_NWAVES];
     __shared__ int ctr[2];
     __shared__ double shf[2];
     __shared__ int stat;
-    float *g = a.x + (size_t)c * HW;
-    for (int i = threadIdx.x; i < HW; i += SC_BLOCK) t.m[(i / W) * t.LW + (i % W)] = g[i];
+    if (!GT)
+        for (int i = threadIdx.x; i < HW; i += SC_BLOCK) t.m[(i / W) * t.LW + (i % W)] = g[i];
     if (threadIdx.x == 0) stat = 0;
     __syncthreads();
     const int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
-    bool writeback = true;
+    bool writeback = !GT;
     switch (a.op) {
     case OP_MONO_WEIGHTED: monotonic_tile<false, float>(t, cy, cx, a.thresh); break;
     case OP_MONO_NEAREST:  monotonic_tile<true, float>(t, cy, cx, a.thresh); break;
@@ -204,11 +209,22 @@ static int launch_operator(OpArgs a, void *stream)
         if (rc) return rc;
         hipLaunchKernelGGL(k_operator_w, dim3((a.n + SC_NWAVES - 1) / SC_NWAVES), dim3(SC_BLOCK), lds,
                            (hipStream_t)stream, a);
-    } else {
+    } else if (update_lds_bytes(a.H, a.W) <= LDS_LIMIT) {
         const size_t lds = update_lds_bytes(a.H, a.W);
-        rc = allow_lds(k_operator, lds);
+        rc = allow_lds(k_operator<false>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_operator, dim3(a.n), dim3(SC_BLOCK), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_operator<false>, dim3(a.n), dim3(SC_BLOCK), lds, (hipStream_t)stream, a, (float *)nullptr);
+    } else {
+        if (a.H > 256) return set_err(SCARLET_E_TOO_LARGE, "arrays larger than 256 x 256 are not supported");
+        float *gscratch = nullptr;
+        if (a.op == OP_SYMMETRY)
+            HIP_TRY(hipMalloc(&gscratch, sizeof(float) * (size_t)a.n * round16(a.H) * scratch_stride(round16(a.W))));
+        const size_t lds = sizeof(float) * (2 * round16(a.H) + 5 * round16(a.W));
+        hipLaunchKernelGGL(k_operator<true>, dim3(a.n), dim3(SC_BLOCK), lds, (hipStream_t)stream, a, gscratch);
+        const hipError_t e1 = hipGetLastError();
+        hipError_t e2 = hipSuccess;
+        if (gscratch) { e2 = hipStreamSynchronize((hipStream_t)stream); (void)hipFree(gscratch); }
+        HIP_TRY(e1); HIP_TRY(e2);
     }
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;

@@ -241,3 +241,36 @@ def test_prox_and_normalize(L):
         np.testing.assert_array_equal(m.cpu().numpy()[0], wm)
     with pytest.raises(ValueError):
         L.check(L.lib.scarlet_normalize(L.ptr(s), L.ptr(m), 1, 6, 25, 7, L.stream_ptr()))
+
+
+def test_operators_on_arrays_beyond_the_lds_tile(L):
+    """200 x 256 and 256 x 256 arrays do not fit LDS: the standalone operators then work in place in
+    HBM (k_operator<true>).  Weighted monotonicity, k-space symmetry, max_pixel and the centroid
+    against the CPU oracle."""
+    from oracle import pgm
+    rng = np.random.RandomState(11)
+    for shape in ((200, 256), (256, 256)):
+        c = (rng.randint(40, shape[0] - 40), rng.randint(40, shape[1] - 40))
+        yy, xx = np.mgrid[:shape[0], :shape[1]]
+        X = (np.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2) / 40.) + .02 * rng.randn(*shape)).astype(np.float32)
+        Y = run_op(L, "scarlet_prox_weighted_monotonic", X[None], [c], ctypes.c_float(0.0))[0]
+        ref = X.astype(np.float64).copy()
+        pgm.prox_weighted_monotonic(ref, c, thresh=0.)
+        assert rel_err(Y, ref) < 1e-5
+        sh = rng.uniform(-.5, .5, 2)
+        Y = sym(L, X, c, sh, L.SYM_KSPACE)
+        ref = X.astype(np.float64)
+        pgm.prox_symmetry(ref, c, "kspace", None, tuple(sh))
+        assert rel_err(Y, ref) < 1e-5
+        xs = dev(X[None], torch.float32)
+        cs = dev(np.array([[c[0] + 1, c[1] - 2]]), torch.int32)
+        st = torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.check(L.lib.scarlet_max_pixel(L.ptr(xs), 1, shape[0], shape[1], L.ptr(cs), L.ptr(st), L.stream_ptr()))
+        np.testing.assert_array_equal(cs.cpu().numpy()[0], pgm.max_pixel(X, (c[0] + 1, c[1] - 2)))
+        psf = pgm.default_centroid_weight()
+        shf = torch.zeros((1, 2), dtype=torch.float64, device="cuda")
+        L.check(L.lib.scarlet_psf_weighted_centroid(L.ptr(xs), 1, shape[0], shape[1], L.ptr(dev(psf, torch.float64)), 41,
+                                                    L.ptr(cs), L.ptr(shf), L.ptr(st), L.stream_ptr()))
+        cen, shift = pgm.psf_weighted_centroid(X, psf, tuple(int(v) for v in pgm.max_pixel(X, (c[0] + 1, c[1] - 2))))
+        np.testing.assert_array_equal(cs.cpu().numpy()[0], cen)
+        np.testing.assert_allclose(shf.cpu().numpy()[0], shift, rtol=0, atol=1e-6)
