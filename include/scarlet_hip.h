@@ -33,7 +33,7 @@ extern "C" {
 
 #define SCARLET_OK            0
 #define SCARLET_E_ARG        -1   /* bad shape / null pointer / unsupported option  */
-#define SCARLET_E_TOO_LARGE  -2   /* H*W tile does not fit the 160 KiB LDS budget   */
+#define SCARLET_E_TOO_LARGE  -2   /* frame larger than 256 x 256                    */
 #define SCARLET_E_HIP        -3   /* a HIP runtime call failed (see scarlet_last_error) */
 #define SCARLET_E_NOTIMPL    -4   /* reference raises NotImplementedError here      */
 
@@ -148,6 +148,13 @@ int scarlet_apply_filter(const float *image, int H, int W, const float *values,
 
 /* ------------------------------------------------------------------------------
  * 3. Batched Blend.fit() engine (blend.py:65-223, source.py:402-440)
+ *
+ * Supported shapes: K <= 32 components per scene (K <= 8 when a PSF difference kernel is
+ * set), B <= 8 bands, frames up to 256 x 256.  Which kernels run is an internal choice:
+ * one fused launch per iteration when the K morphology tiles fit LDS (H, W <= 64), the
+ * four-kernel general path otherwise, chunked gradient passes for K > 8, operators in
+ * place in HBM for frames beyond the LDS tile.  Results do not depend on the choice
+ * beyond float32 rounding.
  * ---------------------------------------------------------------------------- */
 
 typedef struct scarlet_batch {
