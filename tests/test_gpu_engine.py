@@ -237,3 +237,42 @@ def test_config5_shape_30_sources_256_l0(BB):
     assert rel_err(b.morph_current[0].cpu().numpy(), np.array([s.morph for s in sc.sources])) < TOL
     assert rel_err(b.sed_current[0].cpu().numpy(), np.array([s.sed for s in sc.sources])) < TOL
     assert rel_err(b.mse(0), sc.mse) < TOL
+
+
+@pytest.mark.parametrize("B,K,H,W,path", [
+    (5, 4, 64, 64, "k_iterate2"),
+    (6, 4, 48, 48, "k_iterate<4,6>"),
+    (5, 3, 96, 80, "general path"),
+    (6, 12, 64, 64, "bigk.h"),
+])
+def test_weights_and_fixed_factors_vs_oracle(BB, B, K, H, W, path):
+    """Per-pixel weights (inverse variance, zeros = masked pixels; observation.py:148-151, 222-247) and
+    fix_sed / fix_morph (blend.py:91-96) through every gradient kernel: 2 scenes, 5 iterations."""
+    from oracle import pgm
+    from scarlet_amd import synth
+    S, iters = 2, 5
+    rng = np.random.RandomState(3)
+    scenes = [synth.make_scene(1300 + i, B=B, H=H, W=W, K=K) for i in range(S)]
+    weights = rng.uniform(0.5, 1.5, size=(S, B, H, W)).astype(np.float32)
+    weights[rng.rand(S, B, H, W) < 0.03] = 0
+    b = BB(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]), weights=weights)
+    b.init_extended(np.ones(B) * 0.1)
+    fs = np.zeros((S, K), np.uint8); fm = np.zeros((S, K), np.uint8)
+    fs[:, 0] = 1; fm[:, 1] = 1
+    b.fix_sed = torch.as_tensor(fs).cuda(); b.fix_morph = torch.as_tensor(fm).cuda()
+    b._fill_struct()
+    sed0 = b.sed_current.cpu().numpy(); morph0 = b.morph_current.cpu().numpy()
+    cen0 = b.centers.cpu().numpy(); sh0 = b.shifts.cpu().numpy()
+    b.fit(iters, e_rel=0)
+    torch.cuda.synchronize()
+    assert int(b.status.abs().sum().item()) == 0
+    worst = 0
+    for i in range(S):
+        sc = pgm.scene_from_state(scenes[i]["images"], sed0[i], morph0[i], cen0[i], sh0[i], weights=weights[i])
+        sc.sources[0].fix_sed = True; sc.sources[1].fix_morph = True
+        pgm.fit(sc, iters, e_rel=0)
+        np.testing.assert_array_equal(b.centers[i].cpu().numpy(), np.array([s.center for s in sc.sources]))
+        worst = max(worst, rel_err(b.morph_current[i].cpu().numpy(), np.array([s.morph for s in sc.sources])),
+                    rel_err(b.sed_current[i].cpu().numpy(), np.array([s.sed for s in sc.sources])),
+                    rel_err(b.mse(i), sc.mse))
+    assert worst < TOL, (path, worst)
