@@ -276,3 +276,36 @@ def test_weights_and_fixed_factors_vs_oracle(BB, B, K, H, W, path):
                     rel_err(b.sed_current[i].cpu().numpy(), np.array([s.sed for s in sc.sources])),
                     rel_err(b.mse(i), sc.mse))
     assert worst < TOL, (path, worst)
+
+
+@pytest.mark.parametrize("sym,mono,l0,l1", [
+    (False, True, None, None), (True, False, None, None), (False, False, None, None),
+    (True, True, 0.3, None), (True, True, None, 0.2), (False, False, 0.3, 0.1),
+])
+@pytest.mark.parametrize("B,K,H,W", [(5, 4, 64, 64), (6, 3, 48, 64), (4, 3, 80, 72)])
+def test_constraint_switches_vs_oracle(BB, B, K, H, W, sym, mono, l0, l1):
+    """PointSource(symmetric=, monotonic=) and the sparsity hooks (source.py:402-440, update.py:71-82)
+    in every combination the kernels branch on: fused 8-wave, fused 4-wave and general path."""
+    from oracle import pgm
+    from scarlet_amd import synth
+    S, iters = 2, 5
+    scenes = [synth.make_scene(1700 + i, B=B, H=H, W=W, K=K) for i in range(S)]
+    b = BB(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]),
+           symmetric=sym, monotonic=mono, l0_thresh=l0, l1_thresh=l1)
+    b.init_extended(np.ones(B) * 0.1)
+    sed0 = b.sed_current.cpu().numpy(); morph0 = b.morph_current.cpu().numpy()
+    cen0 = b.centers.cpu().numpy(); sh0 = b.shifts.cpu().numpy()
+    b.fit(iters, e_rel=0)
+    torch.cuda.synchronize()
+    worst = 0
+    for i in range(S):
+        sc = pgm.scene_from_state(scenes[i]["images"], sed0[i], morph0[i], cen0[i],
+                                  sh0[i] if sym else None, l0_thresh=l0)
+        for s in sc.sources:
+            s.symmetric, s.monotonic, s.l1_thresh = sym, mono, l1
+        pgm.fit(sc, iters, e_rel=0)
+        np.testing.assert_array_equal(b.centers[i].cpu().numpy(), np.array([s.center for s in sc.sources]))
+        worst = max(worst, rel_err(b.morph_current[i].cpu().numpy(), np.array([s.morph for s in sc.sources])),
+                    rel_err(b.sed_current[i].cpu().numpy(), np.array([s.sed for s in sc.sources])),
+                    rel_err(b.mse(i), sc.mse))
+    assert worst < TOL, worst
