@@ -365,15 +365,18 @@ struct UpdateArgs {
     float *gscratch;                  // GT kernels: [S*K][round16(H) * scratch_stride(round16(W))] (T = X B)
 };
 
-// GT = false: the morphology tile and the GEMM scratch live in LDS (tiles up to ~128 x 128).
-// GT = true : frames whose tile does not fit (up to 256 x 256, BASELINE config 5): the same
+// MODE 0/1: the morphology tile lives in LDS (tiles up to ~128 x 128).
+// MODE 2   : frames whose tile does not fit (up to 256 x 256, BASELINE config 5): the same
 //             operators run IN PLACE on the morphology plane in HBM / L2 with the scratch in a
 //             global workspace; only the Hankel vectors are in LDS.  Threads of the workgroup
 //             exchange pixels through global memory across __syncthreads(), exactly as they do
 //             through LDS in the other variant.
-template <bool GT>
+//   MODE 0 tile + GEMM scratch in LDS;  MODE 1 tile in LDS, scratch in HBM (halves the LDS
+//   footprint of a 128 x 128 frame: two workgroups per CU);  MODE 2 both in HBM (the text above)
+template <int MODE>
 __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
 {
+    constexpr bool GT = MODE == 2;
     extern __shared__ __align__(16) float lds[];
     const int c = blockIdx.x, s = c / a.K;
     if (!a.force_it0 && !a.active[s]) return;
@@ -385,6 +388,10 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
         t.LW = W; t.m = nullptr;                    // set below: the plane itself
         scr = a.gscratch + (size_t)c * hp * scratch_stride(wp);
         av = lds;
+    } else if (MODE == 1) {
+        t.LW = tile_stride(W); t.m = lds;
+        scr = a.gscratch + (size_t)c * hp * scratch_stride(wp);
+        av = lds + H * t.LW;
     } else {
         t.LW = tile_stride(W); t.m = lds;
         scr = lds + H * t.LW;

@@ -98,7 +98,7 @@ struct OpArgs {
 };
 
 // GT: arrays whose tile does not fit LDS (up to 256 x 256) are processed in place in HBM, the GEMM
-// scratch of the k-space symmetry in `gscratch` (see k_source_update<true> in engine.h)
+// scratch of the k-space symmetry in `gscratch` (see k_source_update<2> in engine.h)
 template <bool GT>
 __global__ __launch_bounds__(SC_BLOCK) void k_operator(OpArgs a, float *gscratch)
 {
@@ -580,7 +580,8 @@ static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 // frames whose tile does not fit LDS: per-component GEMM scratch of the k-space symmetry in HBM
 static int64_t gscratch_bytes(const scarlet_batch *b)
 {
-    if ((b->H <= 64 && b->W <= 64) || update_lds_bytes(b->H, b->W) <= LDS_LIMIT) return 0;
+    if (b->H <= 64 && b->W <= 64) return 0;
+    if (update_lds_bytes(b->H, b->W) <= 80 * 1024) return 0;      // two workgroups per CU already
     return align256(sizeof(float) * (int64_t)b->S * b->K * round16(b->H) * scratch_stride(round16(b->W)));
 }
 static int64_t base_workspace_bytes(const scarlet_batch *b)
@@ -846,15 +847,24 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
                            (hipStream_t)stream, u);
     } else if (update_lds_bytes(b->H, b->W) <= LDS_LIMIT) {
         const size_t lds = update_lds_bytes(b->H, b->W);
-        rc = allow_lds(k_source_update<false>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_source_update<false>, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
+        const size_t lds1 = sizeof(float) * ((size_t)b->H * tile_stride(b->W) + 2 * round16(b->H) + 5 * round16(b->W));
+        if (lds > 80 * 1024 && lds1 <= 78 * 1024 && gscratch_bytes(b) > 0) {
+            // scratch in HBM: two workgroups per CU instead of one
+            u.gscratch = ws_gscratch(b);
+            rc = allow_lds(k_source_update<1>, lds1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_source_update<1>, dim3(b->S * b->K), dim3(SC_BLOCK), lds1, (hipStream_t)stream, u);
+        } else {
+            rc = allow_lds(k_source_update<0>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_source_update<0>, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
+        }
     } else {
         // frames beyond the LDS tile (up to 256 x 256): operators in place on the plane in HBM / L2
         if (b->H > 256 || b->W > 256) return set_err(SCARLET_E_TOO_LARGE, "frames larger than 256 x 256 are not supported");
         u.gscratch = ws_gscratch(b);
         const size_t lds = sizeof(float) * (2 * round16(b->H) + 5 * round16(b->W));      // av, bv, cv, zv
-        hipLaunchKernelGGL(k_source_update<true>, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
+        hipLaunchKernelGGL(k_source_update<2>, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
     }
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;

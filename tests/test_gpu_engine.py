@@ -181,7 +181,7 @@ def test_other_shapes_vs_oracle(BB, B, K, H, W, path):
 ])
 def test_large_frames_vs_oracle(BB, B, K, H, W, l0):
     """Frames whose morphology tile does not fit LDS (BASELINE config 5 is 256 x 256 with L0
-    sparsity): the constraint operators run in place on the planes in HBM (k_source_update<true>).
+    sparsity): the constraint operators run in place on the planes in HBM (k_source_update<2>).
     The initial state comes from the CPU oracle (the device initialisation keeps a float64 tile in
     LDS and stops at ~140 x 140); 4 iterations, 2 scenes, against the oracle."""
     import copy
@@ -212,7 +212,7 @@ def test_large_frames_vs_oracle(BB, B, K, H, W, l0):
 def test_config5_shape_30_sources_256_l0(BB):
     """BASELINE config 5 at one scene: 6 bands, 256 x 256, 30 overlapping sources (>= 3 px apart),
     symmetry + monotonicity + L0.  Device initialisation (float64 tile in HBM), then 3 iterations
-    through bigk.h + k_source_update<true>, against the CPU oracle from the same initial state."""
+    through bigk.h + k_source_update<2>, against the CPU oracle from the same initial state."""
     from oracle import pgm
     from scarlet_amd import synth
     B, K, H, W, l0 = 6, 30, 256, 256, 0.05

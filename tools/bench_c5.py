@@ -1,5 +1,5 @@
 """BASELINE config 5 timing (not the round's bench line): S scenes of 6 x 256 x 256, K = 30 overlapping sources,
-symmetry + monotonicity + L0; gradient passes of bigk.h, constraints in place in HBM (k_source_update<true>).
+symmetry + monotonicity + L0; gradient passes of bigk.h, constraints in place in HBM (k_source_update<2>).
     python tools/bench_c5.py [--scenes 64] [--steps 5]      (512 scenes over 8 GPUs = 64 per GPU)"""
 import argparse, ctypes, json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
