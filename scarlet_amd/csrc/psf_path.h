@@ -9,7 +9,9 @@
 //     image pixel y  <->  padded, shifted index  (y + o_img) mod F,   o_img = (F-N+1)//2 - F//2
 //     kernel pixel q <->                         (q + o_ker) mod F,   o_ker = (F-P+1)//2 - F//2
 // so the kernels below read/write the FFT buffers directly at those indices -- no separate
-// pad / shift / crop passes.  The transforms themselves are batched hipFFT (rocFFT) R2C / C2R
+// pad / shift / crop passes.  The offsets are taken from the REFERENCE's F (they decide which
+// pixel of an even-sized kernel is its centre); the transforms run at the smallest 7-smooth
+// length >= N + P - 1, which yields the same linear convolution inside the crop (psf_geom).  The transforms themselves are batched hipFFT (rocFFT) R2C / C2R
 // plans over all (scene, band) planes; K-hat is computed once per batch.
 //
 // One iteration with a PSF:
@@ -23,8 +25,9 @@
 #include "engine.h"
 
 struct PsfGeom {
-    int H, W, Fy, Fx, Fxh;       // Fxh = Fx/2 + 1
+    int H, W, Fy, Fx, Fxh;       // device FFT shape, Fxh = Fx/2 + 1
     int oy, ox;                  // image offsets (mod F)
+    int Fry, Frx;                // the REFERENCE's FFT shape: fixes where an even-sized kernel is centred
 };
 
 __host__ __device__ inline int pos_mod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }

@@ -564,16 +564,34 @@ static int check_batch(const scarlet_batch *b)
 static int n_tiles(const scarlet_batch *b) { return (b->H * b->W + SC_TILE_PIX - 1) / SC_TILE_PIX; }
 
 // ---- PSF path geometry (fft.py:68-106: next_fast_len(N + P + 3) per axis, last axis even)
+// FFT shape of the device convolution.  The reference pads to next_fast_len(N + P + 3)
+// (fft.py:68-106: 5-smooth, 3 pixels of slack); the cropped result is the LINEAR convolution, which
+// any length >= N + P - 1 reproduces exactly, so the device takes the smallest 7-smooth length from
+// there (rocFFT has radix-7 kernels: 168 x 168 instead of 180 x 180 for a 128 x 128 frame with a
+// 41 x 41 kernel is 1.56 x faster per transform pair, measured).  Last axis even for the R2C layout.
+static int smooth7_len(int n, bool even)
+{
+    for (int m = n;; ++m) {
+        if (even && (m & 1)) continue;
+        int r = m;
+        for (int p : {2, 3, 5, 7}) while (r % p == 0) r /= p;
+        if (r == 1) return m;
+    }
+}
 static PsfGeom psf_geom(int H, int W, int Py, int Px)
 {
     PsfGeom g;
     g.H = H; g.W = W;
-    g.Fy = scarlet_next_fast_len(H + Py + 3);
-    g.Fx = scarlet_next_fast_len(W + Px + 3);
-    while (g.Fx & 1) g.Fx = scarlet_next_fast_len(g.Fx + 1);
+    g.Fy = smooth7_len(H + Py - 1, false);
+    g.Fx = smooth7_len(W + Px - 1, true);
+    // placement of image and kernel inside the reference's padded arrays (centred pad + ifftshift,
+    // fft.py:27-66): only these parities decide which pixel of an even-sized kernel is its centre
+    g.Fry = scarlet_next_fast_len(H + Py + 3);
+    g.Frx = scarlet_next_fast_len(W + Px + 3);
+    while (g.Frx & 1) g.Frx = scarlet_next_fast_len(g.Frx + 1);
     g.Fxh = g.Fx / 2 + 1;
-    g.oy = (g.Fy - H + 1) / 2 - g.Fy / 2;
-    g.ox = (g.Fx - W + 1) / 2 - g.Fx / 2;
+    g.oy = (g.Fry - H + 1) / 2 - g.Fry / 2;
+    g.ox = (g.Frx - W + 1) / 2 - g.Frx / 2;
     return g;
 }
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -688,7 +706,7 @@ extern "C" int scarlet_batch_prepare_psf(scarlet_batch *b, void *stream)
     hipStream_t st = (hipStream_t)stream;
     float *real = (float *)((char *)b->workspace + l.real);
     float2 *khat = (float2 *)((char *)b->workspace + l.khat);
-    const int oky = (g.Fy - b->psf_h + 1) / 2 - g.Fy / 2, okx = (g.Fx - b->psf_w + 1) / 2 - g.Fx / 2;
+    const int oky = (g.Fry - b->psf_h + 1) / 2 - g.Fry / 2, okx = (g.Frx - b->psf_w + 1) / 2 - g.Frx / 2;
     hipLaunchKernelGGL(k_psf_pad_kernel, dim3(grid_for((int64_t)b->B * g.Fy * g.Fx)), dim3(SC_BLOCK), 0, st,
                        b->diff_kernel, b->B, b->psf_h, b->psf_w, g.Fy, g.Fx, oky, okx, real);
     FftPlans pk;
@@ -765,7 +783,7 @@ extern "C" int scarlet_convolve_same(const float *model, int n, int H, int W, co
     HIP_TRY(hipMalloc((void **)&kreal, nk * plane * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&spec, n * splane * sizeof(float2)));
     HIP_TRY(hipMalloc((void **)&kspec, nk * splane * sizeof(float2)));
-    const int oky = (g.Fy - Py + 1) / 2 - g.Fy / 2, okx = (g.Fx - Px + 1) / 2 - g.Fx / 2;
+    const int oky = (g.Fry - Py + 1) / 2 - g.Fry / 2, okx = (g.Frx - Px + 1) / 2 - g.Frx / 2;
     hipLaunchKernelGGL(k_plane_pad, dim3(grid_for(n * plane)), dim3(SC_BLOCK), 0, st, model, n, H, W, g.Fy, g.Fx, g.oy, g.ox, real);
     hipLaunchKernelGGL(k_psf_pad_kernel, dim3(grid_for(nk * plane)), dim3(SC_BLOCK), 0, st, kernel, nk, Py, Px, g.Fy, g.Fx, oky, okx, kreal);
     FftPlans pm, pk;
