@@ -52,27 +52,40 @@ struct PsfArgs {
     int approximate_L;
 };
 
-// model_b = sum_k sed[k][b] morph[k] written into the padded FFT input plane (a1, a2 + pad)
+// model_b = sum_k sed[k][b] morph[k] written into the padded FFT input planes (a1, a2 + pad).
+// One thread per padded pixel and scene: the K morphology values are read once and all B band
+// planes are written from them.  grid (ceil(Fy Fx / 256), S).
 __global__ __launch_bounds__(SC_BLOCK) void k_psf_model(PsfArgs a)
 {
-    const int plane = blockIdx.y, s = plane / a.B, b = plane - s * a.B;
+    const int s = blockIdx.y;
     if (!a.active[s]) return;
     const PsfGeom g = a.g;
-    const int c0 = a.cur[s], HW = g.H * g.W;
-    __shared__ float sed_s[SC_KMAX];
-    if (threadIdx.x < a.K) sed_s[threadIdx.x] = a.sed[c0][((size_t)s * a.K + threadIdx.x) * a.B + b];
+    const int c0 = a.cur[s], HW = g.H * g.W, K = a.K, B = a.B;
+    __shared__ float sed_s[SC_KMAX * SC_BMAX];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
+        sed_s[(i / B) * SC_BMAX + (i % B)] = a.sed[c0][(size_t)s * K * B + i];
     __syncthreads();
-    const float *mor = a.morph[c0] + (size_t)s * a.K * HW;
-    float *out = a.real + (size_t)plane * g.Fy * g.Fx;
     const int n = g.Fy * g.Fx;
-    for (int i = blockIdx.x * SC_BLOCK + threadIdx.x; i < n; i += gridDim.x * SC_BLOCK) {
-        const int iy = i / g.Fx, ix = i - iy * g.Fx;
-        const int y = pos_mod(iy - g.oy, g.Fy), x = pos_mod(ix - g.ox, g.Fx);
-        float v = 0.f;
-        if (y < g.H && x < g.W)
-            for (int k = 0; k < a.K; ++k) v += sed_s[k] * mor[(size_t)k * HW + y * g.W + x];
-        out[i] = v;
+    const int i = blockIdx.x * SC_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int iy = i / g.Fx, ix = i - iy * g.Fx;
+    const int y = pos_mod(iy - g.oy, g.Fy), x = pos_mod(ix - g.ox, g.Fx);
+    float v[SC_BMAX];
+#pragma unroll
+    for (int b = 0; b < SC_BMAX; ++b) v[b] = 0.f;
+    if (y < g.H && x < g.W) {
+        const float *mor = a.morph[c0] + (size_t)s * K * HW + y * g.W + x;
+        for (int k = 0; k < K; ++k) {
+            const float m = mor[(size_t)k * HW];
+#pragma unroll
+            for (int b = 0; b < SC_BMAX; ++b)
+                if (b < B) v[b] += sed_s[k * SC_BMAX + b] * m;
+        }
     }
+    float *out = a.real + (size_t)s * B * n + i;
+#pragma unroll
+    for (int b = 0; b < SC_BMAX; ++b)
+        if (b < B) out[(size_t)b * n] = v[b];
 }
 
 // spectrum *= K-hat (or its conjugate) * scale ; K-hat is shared by all scenes of a band

@@ -741,7 +741,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
     int rc = get_plans(g.Fy, g.Fx, planes, &p);
     if (rc) return rc;
     prof_start(5, st);
-    hipLaunchKernelGGL(k_psf_model, dim3(grid_for((int64_t)g.Fy * g.Fx), planes), dim3(SC_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_psf_model, dim3((g.Fy * g.Fx + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
     if ((rc = fft_r2c(p, a.real, a.spec, st))) return rc;
     hipLaunchKernelGGL(k_spec_mul, dim3(grid_for((int64_t)planes * plane_elems)), dim3(SC_BLOCK), 0, st,
                        a.spec, a.khat, b->B, plane_elems, (int64_t)planes * plane_elems, 0, scale);
