@@ -176,6 +176,10 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
     # the figure is the one measured with rocprofv3 --pmc passes of this same command and committed
     # under profiles/ (per launch of the same kernel at the same scenes-per-launch), else null.
+    # the fused iteration has two variants (scarlet_hip.hip launch_fused); name the one that ran
+    kernel_label = KERNEL_NAMES[dom]
+    if dom == 4:
+        kernel_label = "k_iterate2<4,5>" if (K <= 4 and B <= 5 and not os.environ.get("SCARLET_FUSED_V1")) else "k_iterate"
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes" if args.traffic_bytes else None
     if traffic is None:
         import glob
@@ -184,7 +188,7 @@ def main():
                 pm = json.load(open(f))
             except Exception:
                 continue
-            if KERNEL_NAMES[dom] in pm.get("kernel", "") and pm.get("scenes_per_launch") == S:
+            if kernel_label.replace(",", ", ") in pm.get("kernel", "") and pm.get("scenes_per_launch") == S:
                 traffic, traffic_src = pm["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
                 break
     out = {
@@ -208,7 +212,7 @@ def main():
                    "active_scenes_after_timed_region": n_active, "scenes_with_status": status_bad,
                    "mean_loss_first_last": [float(mse[:, 0].mean()), float(mse[:, -1].mean())],
                    "host_scene_generation_s": t_gen},
-        "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": kernel_label, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_unit * S, "avg_launch_ms": avg_ms,
