@@ -217,3 +217,30 @@ def test_config3_batch_equals_single_scene_runs(scarlet):
     for i in range(S):
         mi, si, sti, ci = run(images[i:i + 1], centers[i:i + 1])
         assert_array_equal(m[i], mi[0]); assert_array_equal(s[i], si[0]); assert_array_equal(c[i], ci[0])
+
+
+def test_large_frame_with_psf_vs_oracle(scarlet):
+    """PSF path on a frame beyond the LDS tile (3 x 160 x 144, kernel 21 x 21): FFT convolution at
+    the 7-smooth length, gradient kernels, constraints in place in HBM; 3 iterations vs the oracle."""
+    from oracle import pgm
+    from scarlet_amd import synth, fft as fftmod
+    B, H, W, K = 3, 160, 144, 3
+    obs_psfs = np.array([synth.gaussian_psf((21, 21), 1.3 + 0.2 * b) for b in range(B)])
+    model_psf = synth.gaussian_psf((21, 21), 0.9)
+    diff = np.asarray(fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                        fftmod.Fourier(model_psf[None].astype(np.float32))).image, dtype=np.float32)
+    scn = synth.make_scene(2100, B=B, H=H, W=W, K=K, psfs=obs_psfs)
+    init = pgm.make_extended_scene(scn["images"], scn["centers"], np.ones(B) * 0.1,
+                                   obs_psfs=obs_psfs.astype(np.float32), frame_psf=model_psf[None].astype(np.float32))
+    b = scarlet.BlendBatch(scn["images"][None], scn["centers"][None], centroid_weight=model_psf.astype(np.float32))
+    b.set_diff_kernel(diff)
+    b.set_state(np.array([[c.sed for c in init.sources]]), np.array([[c.morph for c in init.sources]]),
+                centers=np.array([[c.center for c in init.sources]]), shifts=np.array([[c.shift for c in init.sources]]))
+    b.fit(3, e_rel=0)
+    torch.cuda.synchronize()
+    assert int(b.status.abs().sum().item()) == 0
+    pgm.fit(init, 3, e_rel=0)
+    assert_array_equal(npy(b.centers[0]), np.array([s.center for s in init.sources]))
+    assert rel_err(npy(b.morph_current[0]), np.array([s.morph for s in init.sources])) < 2e-5
+    assert rel_err(npy(b.sed_current[0]), np.array([s.sed for s in init.sources])) < 2e-5
+    assert rel_err(b.mse(0), init.mse) < 2e-5
