@@ -149,8 +149,8 @@ int scarlet_apply_filter(const float *image, int H, int W, const float *values,
 /* ------------------------------------------------------------------------------
  * 3. Batched Blend.fit() engine (blend.py:65-223, source.py:402-440)
  *
- * Supported shapes: K <= 32 components per scene (K <= 8 when a PSF difference kernel is
- * set), B <= 8 bands, frames up to 256 x 256.  Which kernels run is an internal choice:
+ * Supported shapes: K <= 32 components per scene, B <= 8 bands, frames up to 256 x 256,
+ * with or without a PSF difference kernel.  Which kernels run is an internal choice:
  * one fused launch per iteration when the K morphology tiles fit LDS (H, W <= 64), the
  * four-kernel general path otherwise, chunked gradient passes for K > 8, operators in
  * place in HBM for frames beyond the LDS tile.  Results do not depend on the choice

@@ -19,7 +19,6 @@
 #include "common.h"
 #include "engine.h"
 
-#define SC_KBIG 32
 #define SC_CHUNK 8
 
 // ---- pass 1: model, residual, loss
@@ -304,4 +303,16 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_sed(GradArgs a)
         const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + i / B];
         a.sed[1 - c0][(size_t)s * K * B + i] = fixed ? cur : cur - step_sed * (float)g;
     }
+}
+
+// PSF path with K > 8: the loss of the scene comes from k_psf_resid's per-plane sums; it rides in
+// slot 0 of tile 0 like everywhere else
+__global__ void k_bigk_loss_from_planes(GradArgs a, const double *loss_part)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.S || !a.active[s]) return;
+    const int P = n_partials(a.K, a.B);
+    double l = 0;
+    for (int b = 0; b < a.B; ++b) l += loss_part[s * a.B + b];
+    for (int t = 0; t < a.T; ++t) a.partials[((size_t)s * a.T + t) * P] = t == 0 ? l : 0.0;
 }

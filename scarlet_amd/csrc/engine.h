@@ -16,7 +16,8 @@
 #include "prox_ops.h"
 
 #define SC_TILE_PIX 4096          // pixels per (scene, tile) workgroup in k_grad / k_step
-#define SC_KMAX 8
+#define SC_KMAX 8               // register-tiled gradient kernels
+#define SC_KBIG 32              // chunked gradient kernels (bigk.h)
 #define SC_BMAX 8
 
 __host__ __device__ inline int n_partials(int K, int B) { return 1 + K * B + K * (K + 1) / 2; }

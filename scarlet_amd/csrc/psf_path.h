@@ -61,7 +61,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_psf_model(PsfArgs a)
     if (!a.active[s]) return;
     const PsfGeom g = a.g;
     const int c0 = a.cur[s], HW = g.H * g.W, K = a.K, B = a.B;
-    __shared__ float sed_s[SC_KMAX * SC_BMAX];
+    __shared__ float sed_s[SC_KBIG * SC_BMAX];
     for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
         sed_s[(i / B) * SC_BMAX + (i % B)] = a.sed[c0][(size_t)s * K * B + i];
     __syncthreads();

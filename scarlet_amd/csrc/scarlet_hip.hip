@@ -550,8 +550,6 @@ static int check_batch(const scarlet_batch *b)
     if (b->S <= 0 || b->K <= 0 || b->B <= 0 || b->H <= 0 || b->W <= 0) return set_err(SCARLET_E_ARG, "bad batch shape");
     if (b->K > SC_KBIG || b->B > SC_BMAX)
         return set_err(SCARLET_E_NOTIMPL, "K > 32 or B > 8 not supported by this build of the gradient kernels");
-    if (b->K > SC_KMAX && b->diff_kernel)
-        return set_err(SCARLET_E_NOTIMPL, "K > 8 with a PSF difference kernel is not supported yet");
     if (b->W > 256) return set_err(SCARLET_E_TOO_LARGE, "W > 256 unsupported");
     if (!b->images || !b->sed[0] || !b->sed[1] || !b->morph[0] || !b->morph[1] || !b->cur || !b->centers ||
         !b->shifts || !b->flags || !b->lipschitz || !b->mse || !b->it || !b->active || !b->status || !b->workspace)
@@ -753,6 +751,25 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
     if ((rc = fft_c2r(p, a.spec, a.real, st))) return rc;
     prof_stop(st);
     dim3 grid(a.T, a.S);
+    if (b->K > SC_KMAX) {
+        // many components: G is cropped out of the FFT buffers once, then the chunked passes of bigk.h
+        GradArgs ga = grad_args(b, approximate_L);
+        float *resid = ws_resid(b);
+        const int nch = (b->K + SC_CHUNK - 1) / SC_CHUNK;
+        prof_start(0, st);
+        hipLaunchKernelGGL(k_plane_crop, dim3(grid_for((int64_t)planes * b->H * b->W)), dim3(SC_BLOCK), 0, st,
+                           (const float *)a.real, planes, b->H, b->W, g.Fy, g.Fx, g.oy, g.ox, resid);
+        hipLaunchKernelGGL(k_bigk_loss_from_planes, dim3((b->S + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0, st, ga,
+                           (const double *)a.loss_part);
+        hipLaunchKernelGGL(k_bigk_gram, dim3(ga.T, nch * (nch + 1) / 2, ga.S), dim3(SC_BLOCK), 0, st, ga);
+        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(ga.S), dim3(SC_WAVE), 0, st, ga);
+        prof_stop(st); prof_start(1, st);
+        hipLaunchKernelGGL(k_bigk_step, dim3(ga.T, nch, ga.S), dim3(SC_BLOCK), 0, st, ga, (const float *)resid);
+        hipLaunchKernelGGL(k_bigk_sed, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga);
+        prof_stop(st);
+        HIP_TRY(hipGetLastError());
+        return SCARLET_OK;
+    }
     if (b->K <= 4) {
         prof_start(0, st);
         hipLaunchKernelGGL((k_grad_psf<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
