@@ -146,6 +146,13 @@ int scarlet_apply_filter(const float *image, int H, int W, const float *values,
                          const int32_t *y_start, const int32_t *y_end, const int32_t *x_start,
                          const int32_t *x_end, int n, float *result, void *stream);
 
+/* fft.match_psfs (fft.py:282-301) for n PSFs on the device: out[i] = the difference kernel that
+   turns psf2[i] (or psf2[0] when n2 == 1) into psf1[i]: ratio of the spectra at the reference's
+   FFT shape next_fast_len(P1 + P2 + 3) (last axis even), cropped to psf1's shape.
+   psf1 [n][P1y][P1x], psf2 [n2][P2y][P2x], out [n][P1y][P1x], all device float32. */
+int scarlet_match_psfs(const float *psf1, int n, int P1y, int P1x, const float *psf2, int n2,
+                       int P2y, int P2x, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------
  * 3. Batched Blend.fit() engine (blend.py:65-223, source.py:402-440)
  *
@@ -189,11 +196,14 @@ typedef struct scarlet_batch {
     float l0_thresh, l1_thresh;  /* < 0 -> off; else update.sparse_l0/l1 before positive */
     const double *centroid_psf;  /* [P][P] float64 centroid weight (source.py:483-490) */
     int32_t centroid_P;
-    /* PSF difference kernel of Observation.match (observation.py:191-194), shared by all
-       scenes: [B][psf_h][psf_w] or NULL (render = identity).  When set, call
-       scarlet_batch_prepare_psf() once before fitting (and again if it changes).        */
+    /* PSF difference kernel of Observation.match (observation.py:191-194): NULL (render =
+       identity), [B][psf_h][psf_w] shared by all scenes (diff_kernel_per_scene = 0), or one
+       set per scene [S][B][psf_h][psf_w] (diff_kernel_per_scene = 1: every scene was observed
+       with its own PSFs).  When set, call scarlet_batch_prepare_psf() once before fitting
+       (and again if it changes).                                                         */
     const float *diff_kernel;
     int32_t psf_h, psf_w;
+    int32_t diff_kernel_per_scene;
     /* workspace owned by the caller: scarlet_batch_workspace_bytes() bytes            */
     void *workspace;
 } scarlet_batch;

@@ -48,6 +48,7 @@ class ScarletBatch(Structure):
         ("l0_thresh", c_float), ("l1_thresh", c_float),
         ("centroid_psf", c_void_p), ("centroid_P", c_int32),
         ("diff_kernel", c_void_p), ("psf_h", c_int32), ("psf_w", c_int32),
+        ("diff_kernel_per_scene", c_int32),
         ("workspace", c_void_p),
     ]
 
@@ -66,6 +67,7 @@ _SIGNATURES = {
     "scarlet_prox_symmetry": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_float, c_int, c_float, _P]),
     "scarlet_max_pixel": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "scarlet_psf_weighted_centroid": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    "scarlet_match_psfs": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P]),
     "scarlet_prox_plus": (c_int, [_P, c_int64, _P]),
     "scarlet_prox_hard": (c_int, [_P, c_int64, c_float, _P]),
     "scarlet_prox_soft": (c_int, [_P, c_int64, c_float, _P]),

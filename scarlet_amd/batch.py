@@ -124,15 +124,19 @@ class BlendBatch(object):
             self.shifts.copy_(t.as_tensor(np.asarray(shifts, dtype=np.float64)).to(self.shifts))
 
     def set_diff_kernel(self, kernel):
-        """PSF difference kernel (B, Py, Px) shared by all scenes (what Observation.match
-        computes, reference observation.py:191-194).  Enables the FFT-convolution render
-        (row a3b): grows the workspace by the FFT buffers and transforms the kernel once."""
+        """PSF difference kernel (what Observation.match computes, reference observation.py:191-194):
+        (B, Py, Px) shared by all scenes, or (S, B, Py, Px) when every scene was observed with its own
+        PSFs (`fft.match_psfs_device` makes them in one call).  Enables the FFT-convolution render
+        (row a3b): grows the workspace by the FFT buffers and transforms the kernels once."""
         t = self.torch
         k = (kernel if t.is_tensor(kernel) else t.as_tensor(np.ascontiguousarray(kernel, dtype=np.float32)))
         self.diff_kernel = k.to(device=self.device, dtype=t.float32).contiguous()
-        assert self.diff_kernel.ndim == 3 and self.diff_kernel.shape[0] == self.B
+        per_scene = self.diff_kernel.ndim == 4
+        assert (self.diff_kernel.ndim == 3 and self.diff_kernel.shape[0] == self.B) or \
+               (per_scene and tuple(self.diff_kernel.shape[:2]) == (self.S, self.B))
         self._c.diff_kernel = self.diff_kernel.data_ptr()
-        self._c.psf_h, self._c.psf_w = int(self.diff_kernel.shape[1]), int(self.diff_kernel.shape[2])
+        self._c.diff_kernel_per_scene = int(per_scene)
+        self._c.psf_h, self._c.psf_w = int(self.diff_kernel.shape[-2]), int(self.diff_kernel.shape[-1])
         nbytes = _lib.lib.scarlet_batch_workspace_bytes(ctypes.byref(self._c))
         self.workspace = t.zeros((int(nbytes),), dtype=t.uint8, device=self.device)
         self._c.workspace = self.workspace.data_ptr()

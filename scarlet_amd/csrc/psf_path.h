@@ -88,13 +88,14 @@ __global__ __launch_bounds__(SC_BLOCK) void k_psf_model(PsfArgs a)
         if (b < B) out[(size_t)b * n] = v[b];
 }
 
-// spectrum *= K-hat (or its conjugate) * scale ; K-hat is shared by all scenes of a band
-__global__ void k_spec_mul(float2 *spec, const float2 *khat, int B, int plane_elems, int64_t total,
+// spectrum *= K-hat (or its conjugate) * scale ; K-hat has `nk` planes: B (shared by all scenes of a
+// band) or S * B (one kernel set per scene)
+__global__ void k_spec_mul(float2 *spec, const float2 *khat, int nk, int plane_elems, int64_t total,
                            int conj, float scale)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int plane = (int)(i / plane_elems), e = (int)(i - (int64_t)plane * plane_elems);
-        const float2 k = khat[(size_t)(plane % B) * plane_elems + e];
+        const float2 k = khat[(size_t)(plane % nk) * plane_elems + e];
         const float2 v = spec[i];
         const float ki = conj ? -k.y : k.y;
         spec[i] = make_float2((v.x * k.x - v.y * ki) * scale, (v.x * ki + v.y * k.x) * scale);
@@ -331,5 +332,17 @@ __global__ void k_plane_crop(const float *in, int n, int H, int W, int Fy, int F
         const int p = (int)(i / ((int64_t)H * W)), e = (int)(i - (int64_t)p * H * W);
         const int y = e / W, x = e - y * W;
         out[i] = in[((size_t)p * Fy + pos_mod(y + oy, Fy)) * Fx + pos_mod(x + ox, Fx)];
+    }
+}
+
+// spectrum ratio a / b (fft.match_psfs): b has nb planes (1: the same for every plane of a)
+__global__ void k_spec_div(float2 *a, const float2 *b, int nb, int plane_elems, int64_t total, float scale)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int plane = (int)(i / plane_elems), e = (int)(i - (int64_t)plane * plane_elems);
+        const float2 d = b[(size_t)(plane % nb) * plane_elems + e];
+        const float2 v = a[i];
+        const float den = d.x * d.x + d.y * d.y;
+        a[i] = make_float2((v.x * d.x + v.y * d.y) / den * scale, (v.y * d.x - v.x * d.y) / den * scale);
     }
 }

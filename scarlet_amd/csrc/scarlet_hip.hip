@@ -618,7 +618,7 @@ static PsfLayout psf_layout(const scarlet_batch *b)
     l.real = l.loss + align256(planes * (int64_t)sizeof(double));
     l.spec = l.real + align256(planes * g.Fy * g.Fx * (int64_t)sizeof(float));
     l.khat = l.spec + align256(planes * g.Fy * g.Fxh * (int64_t)sizeof(float2));
-    l.total = l.khat + align256((int64_t)b->B * g.Fy * g.Fxh * (int64_t)sizeof(float2));
+    l.total = l.khat + align256((b->diff_kernel_per_scene ? planes : (int64_t)b->B) * g.Fy * g.Fxh * (int64_t)sizeof(float2));
     return l;
 }
 
@@ -705,10 +705,11 @@ extern "C" int scarlet_batch_prepare_psf(scarlet_batch *b, void *stream)
     float *real = (float *)((char *)b->workspace + l.real);
     float2 *khat = (float2 *)((char *)b->workspace + l.khat);
     const int oky = (g.Fry - b->psf_h + 1) / 2 - g.Fry / 2, okx = (g.Frx - b->psf_w + 1) / 2 - g.Frx / 2;
-    hipLaunchKernelGGL(k_psf_pad_kernel, dim3(grid_for((int64_t)b->B * g.Fy * g.Fx)), dim3(SC_BLOCK), 0, st,
-                       b->diff_kernel, b->B, b->psf_h, b->psf_w, g.Fy, g.Fx, oky, okx, real);
+    const int nk = b->diff_kernel_per_scene ? b->S * b->B : b->B;
+    hipLaunchKernelGGL(k_psf_pad_kernel, dim3(grid_for((int64_t)nk * g.Fy * g.Fx)), dim3(SC_BLOCK), 0, st,
+                       b->diff_kernel, nk, b->psf_h, b->psf_w, g.Fy, g.Fx, oky, okx, real);
     FftPlans pk;
-    if ((rc = get_plans(g.Fy, g.Fx, b->B, &pk))) return rc;
+    if ((rc = get_plans(g.Fy, g.Fx, nk, &pk))) return rc;
     if ((rc = fft_r2c(pk, real, khat, st))) return rc;
     FftPlans pb;
     if ((rc = get_plans(g.Fy, g.Fx, b->S * b->B, &pb))) return rc;     // create the big plans now
@@ -735,6 +736,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
     const int planes = b->S * b->B;
     const int plane_elems = g.Fy * g.Fxh;
     const float scale = 1.0f / ((float)g.Fy * (float)g.Fx);
+    const int nkh = b->diff_kernel_per_scene ? planes : b->B;
     FftPlans p;
     int rc = get_plans(g.Fy, g.Fx, planes, &p);
     if (rc) return rc;
@@ -742,12 +744,12 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
     hipLaunchKernelGGL(k_psf_model, dim3((g.Fy * g.Fx + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
     if ((rc = fft_r2c(p, a.real, a.spec, st))) return rc;
     hipLaunchKernelGGL(k_spec_mul, dim3(grid_for((int64_t)planes * plane_elems)), dim3(SC_BLOCK), 0, st,
-                       a.spec, a.khat, b->B, plane_elems, (int64_t)planes * plane_elems, 0, scale);
+                       a.spec, a.khat, nkh, plane_elems, (int64_t)planes * plane_elems, 0, scale);
     if ((rc = fft_c2r(p, a.spec, a.real, st))) return rc;
     hipLaunchKernelGGL(k_psf_resid, dim3(planes), dim3(SC_BLOCK), 0, st, a);
     if ((rc = fft_r2c(p, a.real, a.spec, st))) return rc;
     hipLaunchKernelGGL(k_spec_mul, dim3(grid_for((int64_t)planes * plane_elems)), dim3(SC_BLOCK), 0, st,
-                       a.spec, a.khat, b->B, plane_elems, (int64_t)planes * plane_elems, 1, scale);
+                       a.spec, a.khat, nkh, plane_elems, (int64_t)planes * plane_elems, 1, scale);
     if ((rc = fft_c2r(p, a.spec, a.real, st))) return rc;
     prof_stop(st);
     dim3 grid(a.T, a.S);
@@ -784,6 +786,45 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
         prof_stop(st);
     }
     HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
+}
+
+extern "C" int scarlet_match_psfs(const float *psf1, int n, int P1y, int P1x, const float *psf2, int n2,
+                                  int P2y, int P2x, float *out, void *stream)
+{
+    if (!psf1 || !psf2 || !out || n <= 0 || (n2 != n && n2 != 1) || P1y <= 0 || P1x <= 0 || P2y <= 0 || P2x <= 0)
+        return set_err(SCARLET_E_ARG, "bad match_psfs arguments");
+    // fft._get_fft_shape(psf1, psf2, padding=3): 5-smooth length of the SUM of the sizes + 3, last axis even.
+    // (A spectrum ratio is a deconvolution on the periodic domain: unlike the convolutions of the fit it
+    // depends on the FFT shape, so the reference's shape is used as is.)
+    const int Fy = scarlet_next_fast_len(P1y + P2y + 3);
+    int Fx = scarlet_next_fast_len(P1x + P2x + 3);
+    while (Fx & 1) Fx = scarlet_next_fast_len(Fx + 1);
+    const int64_t plane = (int64_t)Fy * Fx, splane = (int64_t)Fy * (Fx / 2 + 1);
+    hipStream_t st = (hipStream_t)stream;
+    float *r1 = nullptr, *r2 = nullptr; float2 *s1 = nullptr, *s2 = nullptr;
+    HIP_TRY(hipMalloc((void **)&r1, n * plane * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&r2, n2 * plane * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&s1, n * splane * sizeof(float2)));
+    HIP_TRY(hipMalloc((void **)&s2, n2 * splane * sizeof(float2)));
+    const int o1y = (Fy - P1y + 1) / 2 - Fy / 2, o1x = (Fx - P1x + 1) / 2 - Fx / 2;
+    const int o2y = (Fy - P2y + 1) / 2 - Fy / 2, o2x = (Fx - P2x + 1) / 2 - Fx / 2;
+    hipLaunchKernelGGL(k_plane_pad, dim3(grid_for(n * plane)), dim3(SC_BLOCK), 0, st, psf1, n, P1y, P1x, Fy, Fx, o1y, o1x, r1);
+    hipLaunchKernelGGL(k_plane_pad, dim3(grid_for(n2 * plane)), dim3(SC_BLOCK), 0, st, psf2, n2, P2y, P2x, Fy, Fx, o2y, o2x, r2);
+    FftPlans pa, pb;
+    int rc;
+    if ((rc = get_plans(Fy, Fx, n, &pa)) == SCARLET_OK && (rc = get_plans(Fy, Fx, n2, &pb)) == SCARLET_OK &&
+        (rc = fft_r2c(pa, r1, s1, st)) == SCARLET_OK && (rc = fft_r2c(pb, r2, s2, st)) == SCARLET_OK) {
+        hipLaunchKernelGGL(k_spec_div, dim3(grid_for(n * splane)), dim3(SC_BLOCK), 0, st, s1, (const float2 *)s2, n2,
+                           (int)splane, n * splane, 1.0f / ((float)Fy * (float)Fx));
+        if ((rc = fft_c2r(pa, s1, r1, st)) == SCARLET_OK)
+            hipLaunchKernelGGL(k_plane_crop, dim3(grid_for((int64_t)n * P1y * P1x)), dim3(SC_BLOCK), 0, st,
+                               (const float *)r1, n, P1y, P1x, Fy, Fx, o1y, o1x, out);
+    }
+    const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);
+    (void)hipFree(r1); (void)hipFree(r2); (void)hipFree(s1); (void)hipFree(s2);
+    if (rc) return rc;
+    HIP_TRY(e1); HIP_TRY(e2);
     return SCARLET_OK;
 }
 

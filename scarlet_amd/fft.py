@@ -140,6 +140,28 @@ def match_psfs(psf1, psf2, padding=3, axes=(-2, -1)):
     return Fourier(_from_kspace(spec, F, shape, axes))
 
 
+def match_psfs_device(psf1, psf2):
+    """`match_psfs` on the device for a batch of PSFs: `psf1` (n, P1y, P1x)
+    or (S, B, P1y, P1x), `psf2` (1 | n, P2y, P2x); numpy arrays or device tensors in, device tensor of
+    psf1's shape out.  Same FFT shape and centring as the host function above."""
+    import ctypes
+    from . import _lib
+    torch = _lib.require_gpu()
+    as_t = lambda a: (a if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a))).to(
+        device="cuda", dtype=torch.float32).contiguous()
+    t1, t2 = as_t(psf1), as_t(psf2)
+    shape1 = tuple(t1.shape)
+    t1 = t1.reshape(-1, shape1[-2], shape1[-1])
+    t2 = t2.reshape(-1, t2.shape[-2], t2.shape[-1])
+    if t2.shape[0] not in (1, t1.shape[0]):
+        raise ValueError("psf2 must hold one PSF or one per PSF of psf1")
+    out = torch.empty_like(t1)
+    _lib.check(_lib.lib.scarlet_match_psfs(_lib.ptr(t1), t1.shape[0], t1.shape[1], t1.shape[2],
+                                           _lib.ptr(t2), t2.shape[0], t2.shape[1], t2.shape[2],
+                                           _lib.ptr(out), _lib.stream_ptr()))
+    return out.reshape(shape1)
+
+
 def convolve(image1, image2, padding=3, axes=(-2, -1)):
     """Linear convolution of two `Fourier` images cropped to image1's shape
     (reference fft.convolve, fft.py:304-317).  Host helper for setup and tests."""

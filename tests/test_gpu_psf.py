@@ -272,3 +272,43 @@ def test_many_components_with_psf_vs_oracle(scarlet):
     assert rel_err(npy(b.morph_current[0]), np.array([s.morph for s in sc.sources])) < 2e-5
     assert rel_err(npy(b.sed_current[0]), np.array([s.sed for s in sc.sources])) < 2e-5
     assert rel_err(b.mse(0), sc.mse) < 2e-5
+
+
+def test_match_psfs_on_device_and_per_scene_kernels(scarlet):
+    """fft.match_psfs batched on the device (against the host function, which is
+    pinned on the reference's fixture), and a batch whose scenes each have their own PSFs: every scene
+    must equal its own single-scene run with that scene's kernels."""
+    from scarlet_amd import synth, fft as fftmod
+    B, H, W, K, S = 3, 48, 56, 3, 3
+    model_psf = synth.gaussian_psf((15, 15), 0.9).astype(np.float32)
+    psfs = np.array([[synth.gaussian_psf((15, 15), 1.2 + 0.15 * b + 0.1 * s) for b in range(B)] for s in range(S)],
+                    dtype=np.float32)
+    dev = scarlet.fft.match_psfs_device(psfs, model_psf[None])
+    assert tuple(dev.shape) == (S, B, 15, 15)
+    for s in range(S):
+        host = fftmod.match_psfs(fftmod.Fourier(psfs[s]), fftmod.Fourier(model_psf[None])).image
+        assert rel_err(npy(dev[s]), host) < 1e-5
+    # a different kernel size for psf2, one psf2 per psf1
+    p2 = np.array([synth.gaussian_psf((11, 13), 0.8 + 0.05 * b) for b in range(B)], dtype=np.float32)
+    host = fftmod.match_psfs(fftmod.Fourier(psfs[0]), fftmod.Fourier(p2)).image
+    assert rel_err(npy(scarlet.fft.match_psfs_device(psfs[0], p2)), host) < 1e-5
+
+    scenes = [synth.make_scene(2300 + s, B=B, H=H, W=W, K=K, psfs=psfs[s].astype(np.float64)) for s in range(S)]
+    images = np.stack([sc["images"] for sc in scenes]); centers = np.stack([sc["centers"] for sc in scenes])
+
+    def run(img, cen, kern):
+        b = scarlet.BlendBatch(img, cen, centroid_weight=model_psf)
+        b.set_diff_kernel(kern)
+        b.init_extended(np.ones(B) * 0.1)
+        b.fit(4, e_rel=0)
+        torch.cuda.synchronize()
+        assert int(b.status.abs().sum().item()) == 0
+        return npy(b.morph_current), npy(b.sed_current)
+
+    m, sd = run(images, centers, dev)
+    for s in range(S):
+        ms, ss = run(images[s:s + 1], centers[s:s + 1], dev[s])
+        assert_array_equal(m[s], ms[0]); assert_array_equal(sd[s], ss[0])
+    # and the kernels matter: scene 1 with scene 0's kernels gives a different answer
+    m_wrong, _ = run(images[1:2], centers[1:2], dev[0])
+    assert rel_err(m_wrong[0], m[1]) > 1e-4
