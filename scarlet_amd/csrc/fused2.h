@@ -601,7 +601,8 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         const bool regular = norm > 0.f && !isinf(norm);             // else: the reference's 0/0, x/inf, NaN results
         const float rnorm = 1.0f / norm;
         float4 *out4 = reinterpret_cast<float4 *>(mout_g + (size_t)k * HW);
-        float d2f = 0.f, n2f = 0.f;                      // <= 32 float terms per lane, then f64 across lanes
+        f32x2 d2p = {0.f, 0.f}, n2p = {0.f, 0.f};        // <= 32 float terms per lane, then f64 across lanes
+        const f32x2 rn2 = {rnorm, rnorm}, nm2 = {norm, norm};
         // CUT: zero beyond the sweep's last level; GEN: thresholds and/or an irregular norm
         auto final_pass = [&](auto cut_c, auto gen_c) {
             constexpr bool CUT = decltype(cut_c)::value, GEN = decltype(gen_c)::value;
@@ -612,28 +613,38 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
                 if (g < ngroups) {
                     const float4 v4 = lds_load4(t.m + y * LW + (xq << 2));
                     const float4 l = lastv[j];
-                    float v[4] = {v4.x, v4.y, v4.z, v4.w}, o[4];
-                    const int ay = y < cy ? cy - y : y - cy;
+                    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                    // level(x, y) = 2 max(ax, ay) + min(ax, ay) <= lstop  <=>  ax <= axmax(ay): one
+                    // bound per row instead of a level per pixel
+                    int axmax = 0, xb = 0;
+                    if (CUT) {
+                        const int ay = y < cy ? cy - y : y - cy;
+                        const int h1 = (lstop - ay) >> 1;                      // from 2 ax + ay <= lstop (ax >= ay)
+                        axmax = h1 >= ay ? h1 : lstop - 2 * ay;                // else from 2 ay + ax <= lstop
+                        xb = (xq << 2) - cx + axmax;                           // x - cx + axmax in [0, 2 axmax] <=> |x - cx| <= axmax
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (GEN) v[e] = sparse(v[e]);
                         v[e] = v[e] < 0.f ? 0.f : v[e];                       // NaN stays NaN
-                        if (CUT) {
-                            const int x = (xq << 2) + e, ax = x < cx ? cx - x : x - cx;
-                            if (max(ax, ay) + ax + ay > lstop) v[e] = 0.f;
-                        }
-                        if (GEN && !regular) o[e] = v[e] / norm;
-                        else {
-                            // v / norm, correctly rounded (but for rare double roundings):
-                            // one Newton step on v * (1 / norm)
-                            const float q = v[e] * rnorm;
-                            o[e] = fmaf(fmaf(-q, norm, v[e]), rnorm, q);
-                        }
+                        if (CUT && (axmax < 0 || (unsigned)(xb + e) > (unsigned)(2 * axmax))) v[e] = 0.f;
                     }
-                    out4[g] = make_float4(o[0], o[1], o[2], o[3]);
-                    const float e0 = l.x - o[0], e1 = l.y - o[1], e2 = l.z - o[2], e3 = l.w - o[3];
-                    d2f += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-                    n2f += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                    f32x2 o01, o23;
+                    if (GEN && !regular) {
+                        o01 = (f32x2){v[0] / norm, v[1] / norm}; o23 = (f32x2){v[2] / norm, v[3] / norm};
+                    } else {
+                        // v / norm, correctly rounded (but for rare double roundings): one Newton step
+                        // on v * (1 / norm); two pixels per instruction
+                        const f32x2 a01 = {v[0], v[1]}, a23 = {v[2], v[3]};
+                        const f32x2 q01 = a01 * rn2, q23 = a23 * rn2;
+                        o01 = (a01 - q01 * nm2) * rn2 + q01;
+                        o23 = (a23 - q23 * nm2) * rn2 + q23;
+                    }
+                    const float4 o4 = make_float4(o01.x, o01.y, o23.x, o23.y);
+                    out4[g] = o4;
+                    const f32x2 e01 = (f32x2){l.x, l.y} - o01, e23 = (f32x2){l.z, l.w} - o23;
+                    d2p += e01 * e01; d2p += e23 * e23;
+                    n2p += o01 * o01; n2p += o23 * o23;
                 }
                 y += dyq; xq += dxq;
                 if (xq >= gpr) { xq -= gpr; ++y; }
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         } else {
             final_pass(true_type{}, true_type{});
         }
-        const double d2 = wave_sum((double)d2f), n2 = wave_sum((double)n2f);
+        const double d2 = wave_sum((double)(d2p.x + d2p.y)), n2 = wave_sum((double)(n2p.x + n2p.y));
         if (lane == 0) { conv_m[k][half][0] = d2; conv_m[k][half][1] = n2; }
         if (lead) {
             double d2s = 0, n2s = 0;
