@@ -227,6 +227,13 @@ int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int approximate_L,
 /* _backward + _set_lipschitz + gradient step (blend.py:81-96): reads buffer cur, writes
  * the stepped factors into buffer 1-cur; cur/it are NOT advanced yet                   */
 int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *stream);
+
+/* As scarlet_backward_step, but buffer 1-cur receives the GRADIENTS of the loss -- d loss/d sed
+   [S][K][B] and d loss/d morph [S][K][H*W] (Blend._backward, blend.py:105-118) -- instead of the
+   stepped factors; `lipschitz` and `mse` are written as usual, fix_sed / fix_morph are not applied.
+   For callers that combine gradients themselves: several observations per blend (blend.py:136-137,
+   219-220) and Prior hooks. */
+int scarlet_backward_gradients(scarlet_batch *b, int approximate_L, void *stream);
 /* the built-in constraint pipeline (source.py:402-440).  in_iteration=1: on buffer 1-cur
  * (between backward_step and check_convergence); 0: on buffer cur with it=0 semantics,
  * as the source constructors do (source.py:400,492)                                    */

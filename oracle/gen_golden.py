@@ -341,6 +341,30 @@ def gen_fit_extras(sc):
     out["prior_morph"] = np.array([c.morph for c in blend.components])
     out["prior_mse"] = np.array(blend.mse)
     out["prior_center"] = np.array([c.pixel_center for c in blend.components]).astype(np.int64)
+    # ---- two observations of one 5-band scene (blend.py:120-139, 219-220): bands 0-2 and bands 3-4,
+    # and the same scene observed twice with independent noise; sources initialised from the full cube
+    scn = synth.make_scene(7)
+    images = scn["images"]
+    ch = list("grizy")
+    frame = sc.Frame(images.shape, dtype=np.float32, channels=ch)
+    full = sc.Observation(images, channels=ch).match(frame)
+    cen = [tuple(int(v) for v in p) for p in scn["centers"]]
+    for tag in ("sliced", "twice"):
+        srcs = [sc.ExtendedSource(frame, p, full, bg) for p in cen]
+        if tag == "sliced":
+            obs = [sc.Observation(images[:3], channels=ch[:3]).match(frame),
+                   sc.Observation(images[3:], channels=ch[3:]).match(frame)]
+        else:
+            noise = np.random.RandomState(5).normal(0, 0.1, images.shape).astype(np.float32)
+            out["twice_images2"] = images + noise
+            obs = [sc.Observation(images, channels=ch).match(frame),
+                   sc.Observation(images + noise, channels=ch).match(frame)]
+        blend = sc.Blend(srcs, obs)
+        blend.fit(8, e_rel=0)
+        out[tag + "_sed"] = np.array([c.sed for c in blend.components])
+        out[tag + "_morph"] = np.array([c.morph for c in blend.components])
+        out[tag + "_mse"] = np.array(blend.mse)
+        out[tag + "_center"] = np.array([c.pixel_center for c in blend.components]).astype(np.int64)
     save("fit_extras", **out)
 
 

@@ -704,10 +704,28 @@ def fit(scene, max_iter=200, e_rel=1e-2, approximate_L=False):
     for _ in range(max_iter):
         seds = [c.sed for c in scene.sources]
         morphs = [c.morph for c in scene.sources]
-        loss, gs, gm = loss_and_gradients(seds, morphs, scene.images, scene.weights,
-                                          scene.diff_kernel)
+        extra = getattr(scene, "observations", None)
+        if extra is None:
+            loss, gs, gm = loss_and_gradients(seds, morphs, scene.images, scene.weights,
+                                              scene.diff_kernel)
+            n_obs = 1
+        else:
+            # several observations (blend.py:120-139): the losses add up; an observation sees the
+            # channels of its band slice (observation.py:184-189, 222-224)
+            loss = 0
+            gs = [np.zeros_like(sd) for sd in seds]
+            gm = [np.zeros_like(m) for m in morphs]
+            for ob in extra:
+                sl = ob.get("band_slice", slice(None))
+                l_, gs_, gm_ = loss_and_gradients([sd[sl] for sd in seds], morphs, ob["images"],
+                                                  ob.get("weights", 1), ob.get("diff_kernel"))
+                loss = loss + l_
+                for k in range(len(seds)):
+                    gs[k][sl] += gs_[k]
+                    gm[k] = gm[k] + gm_[k]
+            n_obs = len(extra)
         scene.mse.append(loss)
-        L_sed, L_morph = lipschitz(seds, morphs, 1, approximate_L, scene.mse)
+        L_sed, L_morph = lipschitz(seds, morphs, n_obs, approximate_L, scene.mse)
         for c, g_s, g_m in zip(scene.sources, gs, gm):
             c.L_sed, c.L_morph = L_sed, L_morph
             prior = getattr(c, "prior", None)

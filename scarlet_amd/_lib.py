@@ -76,6 +76,7 @@ _SIGNATURES = {
     "scarlet_batch_workspace_bytes": (c_int64, [POINTER(ScarletBatch)]),
     "scarlet_fit": (c_int, [POINTER(ScarletBatch), c_int, c_double, c_int, c_int, _P]),
     "scarlet_backward_step": (c_int, [POINTER(ScarletBatch), c_int, _P]),
+    "scarlet_backward_gradients": (c_int, [POINTER(ScarletBatch), c_int, _P]),
     "scarlet_source_update": (c_int, [POINTER(ScarletBatch), c_int, _P]),
     "scarlet_check_convergence": (c_int, [POINTER(ScarletBatch), c_double, _P]),
     "scarlet_profile_begin": (c_int, [c_int]),

@@ -61,6 +61,8 @@ class Blend(ComponentTree):
                 return False
             if getattr(s, "prior", None) is not None or hasattr(s, "bboxes"):
                 return False
+        if len(self.observations) != 1 or self.observations[0]._band_slice != slice(None):
+            return False
         sym = {bool(s.symmetric) for s in self.sources}
         mono = {bool(s.monotonic) for s in self.sources}
         return len(sym) == 1 and len(mono) == 1
@@ -70,12 +72,8 @@ class Blend(ComponentTree):
             return self._batch
         torch = _lib.require_gpu()
         from .batch import BlendBatch
-        if len(self.observations) != 1:
-            raise NotImplementedError("fits with several observations are not supported yet "
-                                      "(SURVEY.md 8f rank 4)")
+        multi = len(self.observations) != 1 or self.observations[0]._band_slice != slice(None)
         obs = self.observations[0]
-        if obs._band_slice != slice(None):
-            raise NotImplementedError("band-sliced observations are not supported yet")
         comps = self.components
         centers = []
         for c in comps:
@@ -89,15 +87,31 @@ class Blend(ComponentTree):
                 cw = np.asarray(s._centroid_weight, dtype=np.float64)
                 break
         builtin = self._builtin_pipeline()
-        b = BlendBatch(obs._images_device()[None], np.array(centers, dtype=np.int32)[None],
-                       weights=None if obs._weights_device() is None else obs._weights_device()[None],
-                       symmetric=bool(self.sources[0].symmetric) if builtin else False,
-                       monotonic=bool(self.sources[0].monotonic) if builtin else False,
-                       centroid_weight=cw)
-        if type(obs.weights) is not np.ndarray and obs.weights != 1:
-            b._c.weight_scalar = float(obs.weights)
-        if obs._diff_kernels is not None:
-            b.set_diff_kernel(np.asarray(obs._diff_kernels.image, dtype=np.float32))
+
+        def obs_batch(o, images=None):
+            ob = BlendBatch(o._images_device()[None] if images is None else images,
+                            np.array(centers, dtype=np.int32)[None],
+                            weights=None if (images is not None or o._weights_device() is None) else o._weights_device()[None],
+                            symmetric=bool(self.sources[0].symmetric) if builtin else False,
+                            monotonic=bool(self.sources[0].monotonic) if builtin else False,
+                            centroid_weight=cw)
+            if images is None:
+                if type(o.weights) is not np.ndarray and o.weights != 1:
+                    ob._c.weight_scalar = float(o.weights)
+                if o._diff_kernels is not None:
+                    ob.set_diff_kernel(np.asarray(o._diff_kernels.image, dtype=np.float32))
+            return ob
+
+        self._obs_batches = None
+        if multi:
+            # several observations and / or band slices (reference blend.py:120-139, 219-220): the state
+            # (factors, centres, flags, convergence) lives in a batch over the model frame's channels,
+            # every observation has a gradient-only batch over its own channels
+            C, Ny, Nx = self.frame.shape
+            b = obs_batch(obs, images=torch.zeros((1, C, Ny, Nx), dtype=torch.float32, device="cuda"))
+            self._obs_batches = [(obs_batch(o), o._band_slice) for o in self.observations]
+        else:
+            b = obs_batch(obs)
         sed = torch.stack([c._own_sed for c in comps])[None]
         morph = torch.stack([c._own_morph for c in comps])[None]
         shifts = np.full((1, len(comps), 2), np.nan)
@@ -169,36 +183,64 @@ class Blend(ComponentTree):
         s = _lib.stream_ptr
         b._ensure_mse_capacity(max_iter)
         b.active.fill_(1)
+        multi = self._obs_batches is not None
+        if multi and approximate_L:
+            raise NotImplementedError("approximate_L with several observations")
         for _ in range(max_iter):
             cur = int(b.cur[0].item())
             # Prior hooks (reference blend.py:86-90, component.py:177-187) run on the factors
-            # BEFORE the step: evaluate them now, fold them into the device step afterwards
-            priors = []
+            # BEFORE the step: evaluate them now, add them to the likelihood gradients below
+            priors = {}
             for k, c in enumerate(self.components):
                 if c.prior is not None:
                     self._view_buf = cur
                     c.prior.compute_grad(c)
-                    priors.append((k, c, c._sed.clone(), c._morph.clone()))
-            _lib.check(_lib.lib.scarlet_backward_step(ctypes.byref(b._c), int(bool(approximate_L)), s()))
-            self._view_buf = 1 - cur                     # sources see the stepped factors
-            L = b.lipschitz[0].cpu().numpy()
-            self.L_sed, self.L_morph = float(L[0]), float(L[1])
-            for c in self.components:
-                c.L_sed, c.L_morph = self.L_sed, self.L_morph
-            for k, c, sed0, morph0 in priors:
-                # the device stepped with x - g / L; the likelihood gradient is g = (x - x') L and
-                # the reference's step is x - (g + g_prior) / (L + L_prior)
-                dev = sed0.device
-                as_t = lambda v: v.to(dev) if hasattr(v, "to") else __import__("torch").as_tensor(
-                    np.asarray(v, dtype=np.float32), device=dev)
-                if not c.fix_morph:
-                    g = (morph0 - c._morph) * self.L_morph
-                    c.L_morph = self.L_morph + float(c.prior.L_morph)
-                    c._morph.copy_(morph0 - (g + as_t(c.prior.morph_grad)) / c.L_morph)
-                if not c.fix_sed:
-                    g = (sed0 - c._sed) * self.L_sed
-                    c.L_sed = self.L_sed + float(c.prior.L_sed)
-                    c._sed.copy_(sed0 - (g + as_t(c.prior.sed_grad)) / c.L_sed)
+                    priors[k] = c
+            if not priors and not multi:
+                # plain case: the device takes the step itself
+                _lib.check(_lib.lib.scarlet_backward_step(ctypes.byref(b._c), int(bool(approximate_L)), s()))
+                self._view_buf = 1 - cur                 # sources see the stepped factors
+                L = b.lipschitz[0].cpu().numpy()
+                self.L_sed, self.L_morph = float(L[0]), float(L[1])
+                for c in self.components:
+                    c.L_sed, c.L_morph = self.L_sed, self.L_morph
+            else:
+                # gradients from the device (scarlet_backward_gradients), combination on the host side
+                # of the ABI: sum over observations, L * len(observations) (blend.py:219-220), priors
+                # (component.py:177-187), fix_sed / fix_morph (blend.py:91-96)
+                import torch
+                x_sed, x_morph = b.sed[cur][0], b.morph[cur][0]
+                it_idx = int(b.it[0].item())
+                _lib.check(_lib.lib.scarlet_backward_gradients(ctypes.byref(b._c), int(bool(approximate_L)), s()))
+                L = b.lipschitz[0].cpu().numpy()
+                if multi:
+                    g_sed = torch.zeros_like(x_sed); g_morph = torch.zeros_like(x_morph)
+                    loss = 0.0
+                    for ob, sl in self._obs_batches:
+                        ob.sed[0][0].copy_(x_sed[:, sl]); ob.morph[0][0].copy_(x_morph)
+                        ob.cur.zero_(); ob.it.zero_(); ob.active.fill_(1)
+                        _lib.check(_lib.lib.scarlet_backward_gradients(ctypes.byref(ob._c), 0, s()))
+                        g_sed[:, sl] += ob.sed[1][0]; g_morph += ob.morph[1][0]
+                        loss += float(ob.mse_buf[0, 0].item())
+                    b.mse_buf[0, it_idx] = loss
+                else:
+                    g_sed, g_morph = b.sed[1 - cur][0].clone(), b.morph[1 - cur][0].clone()
+                n_obs = len(self.observations)
+                self.L_sed, self.L_morph = float(L[0]) * n_obs, float(L[1]) * n_obs
+                dev = x_sed.device
+                as_t = lambda v: v.to(dev) if hasattr(v, "to") else torch.as_tensor(np.asarray(v, dtype=np.float32), device=dev)
+                new_sed, new_morph = b.sed[1 - cur][0], b.morph[1 - cur][0]
+                for k, c in enumerate(self.components):
+                    c.L_sed, c.L_morph = self.L_sed, self.L_morph
+                    gs, gm = g_sed[k], g_morph[k]
+                    if k in priors:
+                        if not c.fix_morph:
+                            gm = gm + as_t(c.prior.morph_grad); c.L_morph = self.L_morph + float(c.prior.L_morph)
+                        if not c.fix_sed:
+                            gs = gs + as_t(c.prior.sed_grad); c.L_sed = self.L_sed + float(c.prior.L_sed)
+                    new_sed[k].copy_(x_sed[k] if c.fix_sed else x_sed[k] - (1 / c.L_sed) * gs)
+                    new_morph[k].copy_(x_morph[k] if c.fix_morph else x_morph[k] - (1 / c.L_morph) * gm)
+                self._view_buf = 1 - cur                 # sources see the stepped factors
             self._it_in_progress = int(b.it[0].item()) + 1
             self.update()
             del self._it_in_progress

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_step(GradArgs a, const float 
                     acc[i * SC_BMAX + b] += gb[b] * m;
                     gm += sed_s[i * SC_BMAX + b] * gb[b];
                 }
-                mout[(size_t)k * HW + p] = fixm[i] ? m : m - step_morph * gm;
+                mout[(size_t)k * HW + p] = a.raw_gradient ? gm : (fixm[i] ? m : m - step_morph * gm);
             }
         }
     }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_sed(GradArgs a)
         for (int t = 0; t < a.T; ++t) g += a.partials[((size_t)s * a.T + t) * P + 1 + i];
         const float cur = a.sed[c0][(size_t)s * K * B + i];
         const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + i / B];
-        a.sed[1 - c0][(size_t)s * K * B + i] = fixed ? cur : cur - step_sed * (float)g;
+        a.sed[1 - c0][(size_t)s * K * B + i] = a.raw_gradient ? (float)g : (fixed ? cur : cur - step_sed * (float)g);
     }
 }
 

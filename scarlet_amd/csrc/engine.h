@@ -35,6 +35,7 @@ struct GradArgs {
     int *it;
     const int *active;
     int approximate_L;
+    int raw_gradient;             // 1: write d loss/d sed and d loss/d morph instead of the stepped factors
 };
 
 // ------------------------------------------------------------------------------------
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_step(GradArgs a)
             const int k = i / B;
             const float cur = sed_s[k * BM + (i % B)];
             const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + k];
-            sed_out[(size_t)s * K * B + i] = fixed ? cur : cur - step_sed * (float)tot[1 + i];
+            sed_out[(size_t)s * K * B + i] = a.raw_gradient ? (float)tot[1 + i] : (fixed ? cur : cur - step_sed * (float)tot[1 + i]);
         }
     }
     // morphology step (blend.py:94-96): G recomputed from the streamed tiles
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_step(GradArgs a)
         }
 #pragma unroll
         for (int k = 0; k < KM; ++k)
-            if (k < K) mout[(size_t)k * HW + p] = fixm[k] ? m[k] : m[k] - step_morph * gm[k];
+            if (k < K) mout[(size_t)k * HW + p] = a.raw_gradient ? gm[k] : (fixm[k] ? m[k] : m[k] - step_morph * gm[k]);
     }
     // a.it[s] is advanced by k_converge (every tile of this launch reads the old value)
 }

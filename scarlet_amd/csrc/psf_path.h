@@ -50,6 +50,7 @@ struct PsfArgs {
     int *it;
     const int *active;
     int approximate_L;
+    int raw_gradient;            // as GradArgs::raw_gradient
 };
 
 // model_b = sum_k sed[k][b] morph[k] written into the padded FFT input planes (a1, a2 + pad).
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_step_psf(PsfArgs a)
             const int k = i / B;
             const float curv = sed_s[k * BM + (i % B)];
             const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + k];
-            sed_out[(size_t)s * K * B + i] = fixed ? curv : curv - step_sed * (float)tot[1 + i];
+            sed_out[(size_t)s * K * B + i] = a.raw_gradient ? (float)tot[1 + i] : (fixed ? curv : curv - step_sed * (float)tot[1 + i]);
         }
     const float *mor = a.morph[c0] + (size_t)s * K * HW;
     float *mout = a.morph[1 - c0] + (size_t)s * K * HW;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_step_psf(PsfArgs a)
                 for (int b = 0; b < BM; ++b)
                     if (b < B) gm += sed_s[k * BM + b] * gb[b];      // (entries b >= B of sed_s are never written)
                 const bool fixed = a.fix_morph && a.fix_morph[(size_t)s * K + k];
-                mout[(size_t)k * HW + p] = fixed ? m : m - step_morph * gm;
+                mout[(size_t)k * HW + p] = a.raw_gradient ? gm : (fixed ? m : m - step_morph * gm);
             }
     }
 }

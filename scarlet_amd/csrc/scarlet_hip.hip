@@ -648,6 +648,8 @@ static float *ws_gscratch(const scarlet_batch *b)
     return (float *)((char *)ws_resid(b) + resid);
 }
 
+static thread_local int g_raw_gradient = 0;      // set by scarlet_backward_gradients around scarlet_backward_step
+
 static GradArgs grad_args(const scarlet_batch *b, int approximate_L)
 {
     GradArgs a;
@@ -656,7 +658,7 @@ static GradArgs grad_args(const scarlet_batch *b, int approximate_L)
     a.sed[0] = b->sed[0]; a.sed[1] = b->sed[1]; a.morph[0] = b->morph[0]; a.morph[1] = b->morph[1];
     a.cur = b->cur; a.fix_sed = b->fix_sed; a.fix_morph = b->fix_morph;
     a.partials = ws_partials(b); a.lipschitz = b->lipschitz; a.mse = b->mse; a.mse_capacity = b->mse_capacity;
-    a.it = b->it; a.active = b->active; a.approximate_L = approximate_L;
+    a.it = b->it; a.active = b->active; a.approximate_L = approximate_L; a.raw_gradient = g_raw_gradient;
     return a;
 }
 
@@ -732,7 +734,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
     a.khat = (const float2 *)((char *)b->workspace + l.khat);
     a.partials = ws_partials(b); a.loss_part = (double *)((char *)b->workspace + l.loss);
     a.lipschitz = b->lipschitz; a.mse = b->mse; a.mse_capacity = b->mse_capacity;
-    a.it = b->it; a.active = b->active; a.approximate_L = approximate_L;
+    a.it = b->it; a.active = b->active; a.approximate_L = approximate_L; a.raw_gradient = g_raw_gradient;
     const int planes = b->S * b->B;
     const int plane_elems = g.Fy * g.Fxh;
     const float scale = 1.0f / ((float)g.Fy * (float)g.Fx);
@@ -898,6 +900,14 @@ extern "C" int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *
     }
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;
+}
+
+extern "C" int scarlet_backward_gradients(scarlet_batch *b, int approximate_L, void *stream)
+{
+    g_raw_gradient = 1;
+    const int rc = scarlet_backward_step(b, approximate_L, stream);
+    g_raw_gradient = 0;
+    return rc;
 }
 
 static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void *stream)

@@ -366,3 +366,33 @@ def test_multicomponent_source_matches_the_oracle(scarlet):
     assert rel_err(np.array([npy(c.morph) for c in comps]), g["multi_morph"]) < 2e-5
     assert rel_err(np.array([npy(c.sed) for c in comps]), g["multi_sed"]) < 2e-5
     assert_array_equal(np.array(multi.pixel_center), g["multi_center"])
+
+
+def test_several_observations_match_the_reference(scarlet):
+    """Blend(sources, [obs1, obs2]) (reference blend.py:24-43, 120-139, 219-220): band-sliced
+    observations of one cube and the same scene observed twice, against fixtures generated by the
+    reference (oracle/gen_golden.py gen_fit_extras)."""
+    from scarlet_amd import synth
+    g = load_golden("fit_extras")
+    scn = synth.make_scene(7)
+    images = scn["images"]
+    ch = list("grizy")
+    bg = np.ones(5) * 0.1
+    frame = scarlet.Frame(images.shape, channels=ch)
+    full = scarlet.Observation(images, channels=ch).match(frame)
+    cen = [tuple(int(v) for v in p) for p in scn["centers"]]
+    for tag in ("sliced", "twice"):
+        srcs = [scarlet.ExtendedSource(frame, p, full, bg) for p in cen]
+        if tag == "sliced":
+            obs = [scarlet.Observation(images[:3], channels=ch[:3]).match(frame),
+                   scarlet.Observation(images[3:], channels=ch[3:]).match(frame)]
+        else:
+            obs = [scarlet.Observation(images, channels=ch).match(frame),
+                   scarlet.Observation(g["twice_images2"], channels=ch).match(frame)]
+        blend = scarlet.Blend(srcs, obs)
+        blend.fit(8, e_rel=0)
+        assert blend.it == 8
+        assert rel_err(blend.mse, g[tag + "_mse"]) < 1e-5
+        assert rel_err(np.array([npy(c.morph) for c in blend.components]), g[tag + "_morph"]) < 2e-5
+        assert rel_err(np.array([npy(c.sed) for c in blend.components]), g[tag + "_sed"]) < 2e-5
+        assert_array_equal(np.array([c.pixel_center for c in blend.components]), g[tag + "_center"])

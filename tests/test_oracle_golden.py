@@ -431,3 +431,24 @@ def test_fit_extras_fixture_multicomponent_and_prior():
     assert rel_err(np.array([c.morph for c in sc.sources]), g["prior_morph"]) < 2e-5
     assert rel_err(np.array([c.sed for c in sc.sources]), g["prior_sed"]) < 2e-5
     assert_array_equal(np.array([c.center for c in sc.sources]), g["prior_center"])
+
+
+def test_fit_extras_fixture_several_observations():
+    """Blends with several observations (blend.py:120-139, 219-220): one cube
+    split into band slices 0-2 / 3-4, and the same scene observed twice; reference-generated."""
+    g = load_golden("fit_extras")
+    scn = synth.make_scene(7)
+    images = scn["images"]
+    bg = np.ones(5) * 0.1
+    for tag in ("sliced", "twice"):
+        sc = pgm.make_extended_scene(images, scn["centers"], bg)
+        if tag == "sliced":
+            sc.observations = [dict(images=images[:3], band_slice=slice(0, 3)),
+                               dict(images=images[3:], band_slice=slice(3, 5))]
+        else:
+            sc.observations = [dict(images=images), dict(images=g["twice_images2"])]
+        pgm.fit(sc, 8, e_rel=0)
+        assert rel_err(sc.mse, g[tag + "_mse"]) < 1e-5
+        assert rel_err(np.array([c.morph for c in sc.sources]), g[tag + "_morph"]) < 2e-5
+        assert rel_err(np.array([c.sed for c in sc.sources]), g[tag + "_sed"]) < 2e-5
+        assert_array_equal(np.array([c.center for c in sc.sources]), g[tag + "_center"])
