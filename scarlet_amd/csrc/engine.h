@@ -400,6 +400,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
         av = scr + hp * scratch_stride(wp);
     }
     float *bv = av + 2 * hp, *cv = bv + 2 * wp, *zv = cv + 2 * wp;
+    float *stage = MODE == 0 ? nullptr : zv + wp;   // LDS staging of the operands that live in HBM
     __shared__ double red[SC_NWAVES];
     __shared__ float redf[SC_NWAVES];
     __shared__ int ctr[2];
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
         // update.symmetric(algorithm="kspace") (source.py:432): shift None -> soft, s=1
         const bool none = (dy != dy);
         symmetry_tile(t, cy, cx, none ? SCARLET_SYM_SOFT : SCARLET_SYM_KSPACE, 1.0f, dy, dx,
-                      false, 0.f, scr, av, bv, cv, zv);
+                      false, 0.f, scr, av, bv, cv, zv, stage, GT);
     }
     int lstop = 1 << 30;          // last sweep level computed (early exit); pixels beyond are <= 0 -> 0
     if (a.monotonic) lstop = monotonic_tile<false, float>(t, cy, cx, 0.f, &lastpos);   // source.py:436

@@ -294,9 +294,13 @@ __device__ inline void kspace_vectors(float *av, float *bv, float *cv, int hp, i
     }
 }
 
+// `stage` (LDS, stage_floats(hp, wp) floats, or NULL): used when the tile and/or the scratch live in
+// HBM.  GEMM 1 then reads each 16-row band of X into LDS once (stage_x) instead of once per column
+// tile, GEMM 2 each 16-column band of T once instead of once per row tile.
+__host__ __device__ inline int stage_floats(int hp, int wp) { return max(16 * tile_stride(wp), hp * 16); }
 __device__ inline void kspace_symmetry_tile(const Tile &t, const SymWindow &s, double dy,
                                             double dx, float *scr, float *av, float *bv,
-                                            float *cv, float *zv)
+                                            float *cv, float *zv, float *stage = nullptr, bool stage_x = false)
 {
     float *m = t.m;
     const int LW = t.LW;
@@ -323,6 +327,27 @@ __device__ inline void kspace_symmetry_tile(const Tile &t, const SymWindow &s, d
     const int tiles_x = wp >> 4, tiles = (hp >> 4) * tiles_x;
 
     // GEMM 1: T = Xw (hp x wp, zero outside the window) . Hankel(bv)
+    if (stage && stage_x) {
+        const int SW = tile_stride(wp);
+        for (int i0 = 0; i0 < hp; i0 += 16) {
+            for (int e = threadIdx.x; e < 16 * wp; e += SC_BLOCK) {
+                const int r = e / wp, c = e - r * wp;
+                stage[r * SW + c] = (i0 + r < h && c < w) ? m[(s.y0 + i0 + r) * LW + s.x0 + c] : 0.f;
+            }
+            __syncthreads();
+            for (int tx = wid; tx < tiles_x; tx += SC_NWAVES) {
+                const int j0 = tx << 4;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int k0 = 0; k0 < wp; k0 += 4) {
+                    const int k = k0 + lq;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(stage[lr * SW + k], bv[k + j0 + lr], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[(i0 + lq * 4 + r) * LS + j0 + lr] = acc[r];
+            }
+            __syncthreads();
+        }
+    } else
     for (int tile = wid; tile < tiles; tile += SC_NWAVES) {
         const int i0 = (tile / tiles_x) << 4, j0 = (tile % tiles_x) << 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -351,13 +376,20 @@ __device__ inline void kspace_symmetry_tile(const Tile &t, const SymWindow &s, d
     __syncthreads();
 
     // GEMM 2: Y = Hankel(av) . T ; epilogue combines with X in place
-    for (int tile = wid; tile < tiles; tile += SC_NWAVES) {
+    const int n_outer = stage ? tiles_x : 1;
+    for (int outer = 0; outer < n_outer; ++outer) {
+    if (stage) {
+        for (int e = threadIdx.x; e < hp * 16; e += SC_BLOCK)
+            stage[e] = scr[(e >> 4) * LS + (outer << 4) + (e & 15)];
+        __syncthreads();
+    }
+    for (int tile = stage ? wid * tiles_x + outer : wid; tile < tiles; tile += (stage ? SC_NWAVES * tiles_x : SC_NWAVES)) {
         const int i0 = (tile / tiles_x) << 4, j0 = (tile % tiles_x) << 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int k0 = 0; k0 < hp; k0 += 4) {
             const int k = k0 + lq;
             const float a = av[i0 + lr + k];
-            const float b = scr[k * LS + j0 + lr];
+            const float b = stage ? stage[(k << 4) + lr] : scr[k * LS + j0 + lr];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
         }
         const int j = j0 + lr;
@@ -373,6 +405,8 @@ __device__ inline void kspace_symmetry_tile(const Tile &t, const SymWindow &s, d
             }
         }
     }
+    if (stage) __syncthreads();            // before the next column band overwrites the stage
+    }
     __syncthreads();
 }
 
@@ -380,7 +414,7 @@ __device__ inline void kspace_symmetry_tile(const Tile &t, const SymWindow &s, d
 __device__ inline void symmetry_tile(const Tile &t, int cy, int cx, int algorithm,
                                      float strength, double dy, double dx, bool use_fill,
                                      float fill, float *scr, float *av, float *bv, float *cv,
-                                     float *zv)
+                                     float *zv, float *stage = nullptr, bool stage_x = false)
 {
     SymWindow s = sym_window(t.H, t.W, cy, cx);
     if (algorithm & SCARLET_SYM_FULL_WINDOW) {   // bare operator on the whole array (operator.py:231-288)
@@ -389,7 +423,7 @@ __device__ inline void symmetry_tile(const Tile &t, int cy, int cx, int algorith
     }
     if (algorithm == SCARLET_SYM_KSPACE) {
         if (s.centered) return;          // Appendix A.1: result discarded by the reference
-        kspace_symmetry_tile(t, s, dy, dx, scr, av, bv, cv, zv);
+        kspace_symmetry_tile(t, s, dy, dx, scr, av, bv, cv, zv, stage, stage_x);
     } else {
         flip_symmetry_tile(t, s, algorithm == SCARLET_SYM_SDSS, strength);
     }

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_operator(OpArgs a, float *gscratch
     if (GT) { t.LW = W; t.m = g; scr = gscratch + (size_t)c * hp * scratch_stride(wp); av = lds; }
     else    { t.LW = tile_stride(W); t.m = lds; scr = lds + H * t.LW; av = scr + hp * scratch_stride(wp); }
     float *bv = av + 2 * hp, *cv = bv + 2 * wp, *zv = cv + 2 * wp;
+    float *stage = GT ? zv + wp : nullptr;
     __shared__ double red[SC_NWAVES];
     __shared__ int ctr[2];
     __shared__ double shf[2];
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_operator(OpArgs a, float *gscratch
     case OP_SYMMETRY: {
         const double dy = a.shifts ? a.shifts[2 * c] : 0.0, dx = a.shifts ? a.shifts[2 * c + 1] : 0.0;
         symmetry_tile(t, cy, cx, a.algorithm, a.strength, dy, dx, a.use_fill != 0, a.fill,
-                      scr, av, bv, cv, zv);
+                      scr, av, bv, cv, zv, stage, GT);
         break;
     }
     case OP_MAX_PIXEL:
@@ -219,7 +220,7 @@ static int launch_operator(OpArgs a, void *stream)
         float *gscratch = nullptr;
         if (a.op == OP_SYMMETRY)
             HIP_TRY(hipMalloc(&gscratch, sizeof(float) * (size_t)a.n * round16(a.H) * scratch_stride(round16(a.W))));
-        const size_t lds = sizeof(float) * (2 * round16(a.H) + 5 * round16(a.W));
+        const size_t lds = sizeof(float) * (2 * round16(a.H) + 5 * round16(a.W) + stage_floats(round16(a.H), round16(a.W)));
         hipLaunchKernelGGL(k_operator<true>, dim3(a.n), dim3(SC_BLOCK), lds, (hipStream_t)stream, a, gscratch);
         const hipError_t e1 = hipGetLastError();
         hipError_t e2 = hipSuccess;
@@ -933,7 +934,8 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
                            (hipStream_t)stream, u);
     } else if (update_lds_bytes(b->H, b->W) <= LDS_LIMIT) {
         const size_t lds = update_lds_bytes(b->H, b->W);
-        const size_t lds1 = sizeof(float) * ((size_t)b->H * tile_stride(b->W) + 2 * round16(b->H) + 5 * round16(b->W));
+        const size_t lds1 = sizeof(float) * ((size_t)b->H * tile_stride(b->W) + 2 * round16(b->H) + 5 * round16(b->W) +
+                                             stage_floats(round16(b->H), round16(b->W)));
         if (lds > 80 * 1024 && lds1 <= 78 * 1024 && gscratch_bytes(b) > 0) {
             // scratch in HBM: two workgroups per CU instead of one
             u.gscratch = ws_gscratch(b);
@@ -949,7 +951,8 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
         // frames beyond the LDS tile (up to 256 x 256): operators in place on the plane in HBM / L2
         if (b->H > 256 || b->W > 256) return set_err(SCARLET_E_TOO_LARGE, "frames larger than 256 x 256 are not supported");
         u.gscratch = ws_gscratch(b);
-        const size_t lds = sizeof(float) * (2 * round16(b->H) + 5 * round16(b->W));      // av, bv, cv, zv
+        const size_t lds = sizeof(float) * (2 * round16(b->H) + 5 * round16(b->W) +       // av, bv, cv, zv, stage
+                                            stage_floats(round16(b->H), round16(b->W)));
         hipLaunchKernelGGL(k_source_update<2>, dim3(b->S * b->K), dim3(SC_BLOCK), lds, (hipStream_t)stream, u);
     }
     HIP_TRY(hipGetLastError());
