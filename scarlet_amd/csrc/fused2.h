@@ -14,9 +14,10 @@
 //   sweep        one wave of the pair (its partner waits at the barrier and costs no issue slots)
 //   tail         float4 groups split between the pair
 //
-// The pair is synchronised with workgroup barriers placed outside all divergent code, so
-// every wave executes the same number of them.  Used when K <= 4 (four pairs); other
-// shapes run k_iterate.  Same reference rows as fused.h.
+// The two waves of a pair synchronise with each other only (phase counters in LDS, release /
+// acquire fences, s_sleep while waiting), so the four components of a scene run their chains
+// independently and the workgroup meets again at the end of the constraint phase.  Used when
+// K <= 4 (four pairs) and B <= 5; other shapes run k_iterate.  Same reference rows as fused.h.
 #pragma once
 #include "fused.h"
 
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     __shared__ double conv_s[KM][2], conv_m[KM][2][2];
     __shared__ int lstop_s[KM];
     __shared__ float nmax_s[KM][2];
+    __shared__ int pair_flag[KM][2];           // phase counters of the pair-local synchronisation
     __shared__ unsigned short fl_s[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wid = uniform(tid >> 6);    // wid in an SGPR: scalar branches
     const int c0 = a.cur[s];
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     load_images(0);
     for (int i = tid; i < K * B; i += SC_FB2) sed_s[(i / B) * BM + (i % B)] = sed_in[i];
     ks_fill_lengths(fl_s, tid);
+    if (tid < 2 * KM) (&pair_flag[0][0])[tid] = 0;
     const bool small_side = (K <= B);          // nonzero spectrum of A^T A == that of A A^T
     __syncthreads();                           // sed_s visible
     {
@@ -475,6 +478,17 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     // four sweeps of a scene land on four different SIMDs.
     const int k = wid >> 1, half = wid & 1;
     const bool lead = half == ((k >> 1) & 1);
+    // Synchronisation of the two waves of a pair WITHOUT the other components of the scene: each wave
+    // publishes the phase it has completed (after a release fence on its LDS writes) and sleeps until
+    // its partner has published the same phase.  The four components then run their chains
+    // independently; the workgroup meets again at the end of phase 2.
+    auto pair_sync = [&](int phase) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&pair_flag[k & (KM - 1)][half], phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&pair_flag[k & (KM - 1)][1 - half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase)
+            __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     const bool mine = k < K;
     const int c = s * K + (mine ? k : 0);
     Tile t; t.H = H; t.W = W; t.LW = LW; t.m = tiles + (mine ? k : 0) * tile_floats;
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         }
     }
     STAMP(8);
-    __syncthreads();                                // B1: Hankel vectors complete
+    if (mine) pair_sync(1);                         // B1: Hankel vectors complete
     STAMP(12);
     f32x4 T[4][2];
     if (mine && mode == 1) {
@@ -518,11 +532,11 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         pair_ks_gemm1(t, sw, kg, vec, half, T);
         STAMP(15);
     }
-    __syncthreads();                                // B2: every read of X is done
+    if (mine) pair_sync(2);                         // B2: every read of X is done
     STAMP(13);
     if (mine && mode == 1) pair_ks_gemm2(t, sw, kg, vec, zv, half, T, sy, rank1);
     if (mine && mode == 2 && lead) wave_flip_symmetry<float>(t, sw, false, 1.0f);
-    __syncthreads();                                // B3
+    if (mine) pair_sync(3);                         // B3
     STAMP(9);
     // lane -> (row, float4 group) walk of the final pass without divisions: +128 groups per step
     const int dyq = (2 * SC_WAVE) / gpr, dxq = 2 * SC_WAVE - dyq * gpr;
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         if (lane == 0) { lstop_s[k] = lstop; a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
         load_last();
     }
-    __syncthreads();                                // B4
+    if (mine) pair_sync(4);                         // B4: sweep done, lstop published
     STAMP(10);
     // ---- sparsity, positivity (update.py:71-82, 27-32), normalisation (update.py:62-65),
     // store, convergence sums: one pass over the LDS tile, float4 groups split between the pair
@@ -561,7 +575,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         }
         return v;
     };
-    if (!a.monotonic) {                             // (kernel-uniform branch: barriers inside are safe)
+    if (!a.monotonic) {
         float vmax = -INFINITY;
         bool anynan = false;
         if (mine) {
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
             if (__any(anynan)) vmax = __builtin_nanf("");
             if (lane == 0) nmax_s[k][half] = vmax;
         }
-        __syncthreads();
+        if (mine) pair_sync(5);
         if (mine) {
             const float m0 = nmax_s[k][0], m1 = nmax_s[k][1];
             norm = (m0 != m0 || m1 != m1) ? __builtin_nanf("") : fmaxf(m0, m1);
