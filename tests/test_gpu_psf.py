@@ -312,3 +312,34 @@ def test_match_psfs_on_device_and_per_scene_kernels(scarlet):
     # and the kernels matter: scene 1 with scene 0's kernels gives a different answer
     m_wrong, _ = run(images[1:2], centers[1:2], dev[0])
     assert rel_err(m_wrong[0], m[1]) > 1e-4
+
+
+def test_config3_full_size_properties(scarlet):
+    """BASELINE config 3 at its full batch (4096 scenes of 5 x 128 x 128, 8 sources, PSF 41 x 41):
+    32 distinct scenes tiled to 4096 -- every copy bit-identical wherever it sits, identical to the
+    32-scene run, no status bits, loss decreasing."""
+    from scarlet_amd import synth, fft as fftmod
+    B, H, W, K, U, S, iters = 5, 128, 128, 8, 32, 4096, 3
+    obs_psfs = np.array([synth.gaussian_psf((41, 41), 1.2 + 0.15 * b) for b in range(B)])
+    model_psf = synth.gaussian_psf((41, 41), 0.9)
+    diff = np.asarray(fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                        fftmod.Fourier(model_psf[None].astype(np.float32))).image, dtype=np.float32)
+    scale = (model_psf.max() / obs_psfs.max(axis=(1, 2))).astype(np.float32)
+    scenes = [synth.make_scene(300 + i, B=B, H=H, W=W, K=K, psfs=obs_psfs) for i in range(U)]
+    ui = np.stack([s["images"] for s in scenes]); uc = np.stack([s["centers"] for s in scenes])
+
+    def run(img, cen):
+        b = scarlet.BlendBatch(img, cen, centroid_weight=model_psf.astype(np.float32))
+        b.set_diff_kernel(diff)
+        b.init_extended(np.ones(B) * 0.1, sed_scale=scale)
+        b.fit(iters, e_rel=0)
+        torch.cuda.synchronize()
+        assert int(b.status.abs().sum().item()) == 0
+        return b.morph_current, b.sed_current, b.mse_buf[:, :iters].clone()
+
+    reps = S // U
+    m, s, mse = run(np.tile(ui, (reps, 1, 1, 1)), np.tile(uc, (reps, 1, 1)))
+    ms, ss, mses = run(ui, uc)
+    idx = torch.arange(S, device=m.device) % U
+    assert torch.equal(m, ms[idx]) and torch.equal(s, ss[idx]) and torch.equal(mse, mses[idx])
+    assert bool((mse[:, -1] < mse[:, 0]).all())
