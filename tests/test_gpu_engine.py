@@ -142,8 +142,8 @@ def test_batch_independence_and_determinism(BB):
     (5, 4, 24, 64, "k_iterate2<4,5>, short tile"),
     (6, 4, 64, 64, "k_iterate<4,6>"),
     (8, 3, 40, 40, "k_iterate<4,8>"),
-    (5, 6, 48, 64, "k_iterate<8,6>"),
-    (7, 7, 32, 32, "k_iterate<8,8>"),
+    (5, 6, 48, 64, "general path, wave-level constraints (K > 4)"),
+    (7, 7, 32, 32, "general path, K = B = 7"),
     (5, 3, 96, 80, "general path, workgroup-level constraints (H > 64)"),
     (4, 5, 50, 50, "general path (W % 4 != 0)"),
     (6, 12, 64, 64, "bigk.h: K > 8 in chunks of eight, wave-level constraints"),
