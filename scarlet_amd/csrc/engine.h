@@ -177,6 +177,101 @@ __device__ inline double jacobi_lambda_max(double *A, int n, int ld)
     return l;
 }
 
+// Largest eigenvalue of a symmetric PSD n x n matrix, n <= 4, from its characteristic
+// polynomial in float64:  p(x) = x^4 - c1 x^3 + c2 x^2 - c3 x + c4  with ck = the sum of the
+// k x k principal minors (rows/columns >= n count as zero).  All roots are real and
+// p, p', p'' > 0 to the right of the largest one, so Newton's iteration started at the
+// trace (>= lambda_max) decreases monotonically onto it.  ~10 x fewer dependent
+// instructions than a Jacobi sweep; the root's conditioning is that of the eigenvalue
+// (error ~1e-16 separated, ~1e-8 relative for a double top eigenvalue).
+// Replaces np.linalg.eigvals(...).max() of blend.py:216-218.
+__device__ inline double lambda_max_charpoly4(const double *A, int n, int ld)
+{
+    double m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = (i < n && j < n) ? A[i * ld + j] : 0.0;
+    const double a = m[0][0], b = m[1][1], c = m[2][2], d = m[3][3];
+    const double e = m[0][1], f = m[0][2], g = m[0][3], h = m[1][2], k = m[1][3], l = m[2][3];
+    const double c1 = (a + b) + (c + d);
+    // 2 x 2 minors of rows (0,1) and of rows (2,3), column pairs 01 02 03 12 13 23
+    const double p01 = a * b - e * e, p02 = a * h - e * f, p03 = a * k - e * g;
+    const double p12 = e * h - b * f, p13 = e * k - b * g, p23 = f * k - h * g;
+    const double q01 = f * k - g * h, q02 = f * l - g * c, q03 = f * d - g * l;
+    const double q12 = h * l - k * c, q13 = h * d - k * l, q23 = c * d - l * l;
+    const double c2 = p01 + (a * c - f * f) + (a * d - g * g) + (b * c - h * h) + (b * d - k * k) + q23;
+    // 3 x 3 principal minors
+    const double d012 = c * p01 - h * p02 + f * p12;          // rows/cols 0,1,2 (expansion along row 2)
+    const double d013 = d * p01 - k * p03 + g * p13;          // rows/cols 0,1,3 (along row 3)
+    const double d023 = a * q23 - f * (f * d - l * g) + g * (f * l - c * g);
+    const double d123 = b * q23 - h * (h * d - l * k) + k * (h * l - c * k);
+    const double c3 = (d012 + d013) + (d023 + d123);
+    // Laplace expansion over rows (0,1) x rows (2,3)
+    const double c4 = p01 * q23 - p02 * q13 + p03 * q12 + p12 * q03 - p13 * q02 + p23 * q01;
+    double x = c1;
+    if (!(x > 0.0)) return x;                                  // zero / NaN matrix: 1/L is inf / NaN as in the reference
+    for (int it = 0; it < 64; ++it) {
+        const double pv = (((x - c1) * x + c2) * x - c3) * x + c4;
+        const double dv = ((4.0 * x - 3.0 * c1) * x + 2.0 * c2) * x - c3;
+        if (!(pv > 0.0) || !(dv > 0.0)) break;                 // at (or, by rounding, just past) the root
+        const double dx = pv / dv;
+        x -= dx;
+        if (dx <= 1e-15 * x) break;
+    }
+    return x;
+}
+
+// Largest eigenvalue of an n x n PSD matrix, n <= 8, by ONE wave (all 64 lanes must call): lane (i, j)
+// owns one element.  M = A / tr A is squared 30 times (renormalised by its trace each time), which
+// leaves u1 u1^T up to terms (lambda_i / lambda_1)^(2^30); the Rayleigh quotient of its heaviest
+// column with the ORIGINAL matrix misses lambda_1 by at most n / (e 2^31) relative whatever the
+// spectral gaps (same scheme as k_bigk_lipschitz).  ~10k cycles instead of the ~200k of a single-lane
+// Jacobi on an LDS-resident 8 x 8 matrix.  `buf`: 2 x 64 doubles of LDS owned by the calling wave.
+__device__ inline double wave_lambda_max8(const double *A, int n, int ld, double (*buf)[64])
+{
+    const int lane = threadIdx.x & (SC_WAVE - 1), i = lane >> 3, j = lane & 7;
+    const double a = (i < n && j < n) ? A[i * ld + j] : 0.0;
+    const double tr0 = wave_sum(i == j ? a : 0.0);
+    buf[0][lane] = a / tr0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    int cur = 0;
+    for (int q = 0; q < 30; ++q) {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += buf[cur][(i << 3) + k] * buf[cur][(k << 3) + j];
+        const double t = wave_sum(i == j ? acc : 0.0);
+        buf[1 - cur][lane] = acc * (1.0 / t);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        cur ^= 1;
+    }
+    int best = 0;
+    double bv = buf[cur][0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { const double d = buf[cur][k * 9]; if (d > bv) { bv = d; best = k; } }
+    const double vi = buf[cur][(i << 3) + best], vj = buf[cur][(j << 3) + best];
+    const double num = wave_sum(vi * a * vj), den = wave_sum(j == 0 ? vi * vi : 0.0);
+    return num / den;
+}
+
+// The two Lipschitz constants of a scene from LDS-resident Gram matrices (blend.py:205-218): wave 0
+// takes S S^T (n = K), wave 1 takes A^T A (n = B); n <= 4 uses the characteristic polynomial on one
+// lane.  Every thread of the workgroup must call; results in L[0], L[1] after the trailing barrier.
+__device__ inline void block_lipschitz(double *G, int K, int ldK, double *ATA, int B, int ldB,
+                                       double (*buf)[2][64], double *L)
+{
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wid < 2) {
+        double *M = wid == 0 ? G : ATA;
+        const int n = wid == 0 ? K : B, ld = wid == 0 ? ldK : ldB;
+        double l = 0;
+        if (n <= 4) { if (lane == 0) l = lambda_max_charpoly4(M, n, ld); }
+        else l = wave_lambda_max8(M, n, ld, buf[wid]);
+        if (lane == 0) L[wid] = l;
+    }
+    __syncthreads();
+}
+
 // Register-resident variant for the fused kernel: the whole (padded) N x N matrix lives in
 // VGPRs of ONE lane, loops fully unrolled (no LDS round trips on the rotation chain).
 // Rotation angles are computed in float32 (one v_rcp/v_sqrt each), then (c, s) is
@@ -257,11 +352,11 @@ __global__ __launch_bounds__(SC_BLOCK) void k_step(GradArgs a)
     for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
         sed_s[(i / B) * BM + (i % B)] = sed_in[(size_t)s * K * B + i];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int it_new = a.it[s] + 1;                  // len(mse) after the append
-        const double loss = tot[0];
-        double L_sed, L_morph;
-        if (a.approximate_L) {
+    __shared__ double Lc[2];
+    __shared__ double eigbuf[2][2][64];
+    const int it_new = a.it[s] + 1;                      // len(mse) after the append
+    if (a.approximate_L) {
+        if (threadIdx.x == 0) {
             // blend.py:189-202: traces of the two Gram matrices, doubled if the loss rose
             double LA = 0, LS = 0;
             int go = 0;
@@ -269,32 +364,34 @@ __global__ __launch_bounds__(SC_BLOCK) void k_step(GradArgs a)
                 for (int k2 = k; k2 < K; ++k2) { if (k2 == k) LA += tot[1 + K * B + go]; ++go; }
             for (int k = 0; k < K; ++k)
                 for (int b = 0; b < B; ++b) LS += (double)sed_s[k * BM + b] * sed_s[k * BM + b];
-            if (it_new > 1 && loss > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { LA *= 2; LS *= 2; }
-            L_sed = LA; L_morph = LS;
-        } else {
-            // blend.py:205-218: L_sed = lambda_max(S S^T), L_morph = lambda_max(A^T A)
-            double *G = mat, *ATA = mat + KM * KM;
-            int go = 0;
-            for (int k = 0; k < K; ++k)
-                for (int k2 = k; k2 < K; ++k2) {
-                    G[k * KM + k2] = G[k2 * KM + k] = tot[1 + K * B + go]; ++go;
-                }
-            for (int b = 0; b < B; ++b)
-                for (int b2 = 0; b2 < B; ++b2) {
-                    double r = 0;
-                    for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
-                    ATA[b * BM + b2] = r;
-                }
-            L_sed = jacobi_lambda_max(G, K, KM);
-            L_morph = jacobi_lambda_max(ATA, B, BM);
+            if (it_new > 1 && tot[0] > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { LA *= 2; LS *= 2; }
+            Lc[0] = LA; Lc[1] = LS;
         }
+        __syncthreads();
+    } else {
+        // blend.py:205-218: L_sed = lambda_max(S S^T), L_morph = lambda_max(A^T A)
+        double *G = mat, *ATA = mat + KM * KM;
+        for (int i = threadIdx.x; i < K * K; i += SC_BLOCK) {
+            const int k = i / K, k2 = i - k * K, lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
+            G[k * KM + k2] = tot[1 + K * B + lo * K - (lo * (lo - 1)) / 2 + (hi - lo)];
+        }
+        for (int i = threadIdx.x; i < B * B; i += SC_BLOCK) {
+            const int b = i / B, b2 = i - b * B;
+            double r = 0;
+            for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
+            ATA[b * BM + b2] = r;
+        }
+        __syncthreads();
+        block_lipschitz(G, K, KM, ATA, B, BM, eigbuf, Lc);
+    }
+    if (threadIdx.x == 0) {
         // frame dtype is float32: the reference's L and 1/L are float32 scalars
-        step_s[0] = 1.0f / (float)L_sed;
-        step_s[1] = 1.0f / (float)L_morph;
+        step_s[0] = 1.0f / (float)Lc[0];
+        step_s[1] = 1.0f / (float)Lc[1];
         if (tile == 0) {
-            if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
-            a.lipschitz[2 * s] = L_sed;
-            a.lipschitz[2 * s + 1] = L_morph;
+            if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = tot[0];
+            a.lipschitz[2 * s] = Lc[0];
+            a.lipschitz[2 * s + 1] = Lc[1];
         }
     }
     __syncthreads();

@@ -54,51 +54,6 @@ __device__ __forceinline__ float4 lds_load4(const float *p)
     return make_float4(a.x, a.y, b.x, b.y);
 }
 
-// Largest eigenvalue of a symmetric PSD n x n matrix, n <= 4, from its characteristic
-// polynomial in float64:  p(x) = x^4 - c1 x^3 + c2 x^2 - c3 x + c4  with ck = the sum of the
-// k x k principal minors (rows/columns >= n count as zero).  All roots are real and
-// p, p', p'' > 0 to the right of the largest one, so Newton's iteration started at the
-// trace (>= lambda_max) decreases monotonically onto it.  ~10 x fewer dependent
-// instructions than a Jacobi sweep; the root's conditioning is that of the eigenvalue
-// (error ~1e-16 separated, ~1e-8 relative for a double top eigenvalue).
-// Replaces np.linalg.eigvals(...).max() of blend.py:216-218.
-__device__ inline double lambda_max_charpoly4(const double *A, int n, int ld)
-{
-    double m[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) m[i][j] = (i < n && j < n) ? A[i * ld + j] : 0.0;
-    const double a = m[0][0], b = m[1][1], c = m[2][2], d = m[3][3];
-    const double e = m[0][1], f = m[0][2], g = m[0][3], h = m[1][2], k = m[1][3], l = m[2][3];
-    const double c1 = (a + b) + (c + d);
-    // 2 x 2 minors of rows (0,1) and of rows (2,3), column pairs 01 02 03 12 13 23
-    const double p01 = a * b - e * e, p02 = a * h - e * f, p03 = a * k - e * g;
-    const double p12 = e * h - b * f, p13 = e * k - b * g, p23 = f * k - h * g;
-    const double q01 = f * k - g * h, q02 = f * l - g * c, q03 = f * d - g * l;
-    const double q12 = h * l - k * c, q13 = h * d - k * l, q23 = c * d - l * l;
-    const double c2 = p01 + (a * c - f * f) + (a * d - g * g) + (b * c - h * h) + (b * d - k * k) + q23;
-    // 3 x 3 principal minors
-    const double d012 = c * p01 - h * p02 + f * p12;          // rows/cols 0,1,2 (expansion along row 2)
-    const double d013 = d * p01 - k * p03 + g * p13;          // rows/cols 0,1,3 (along row 3)
-    const double d023 = a * q23 - f * (f * d - l * g) + g * (f * l - c * g);
-    const double d123 = b * q23 - h * (h * d - l * k) + k * (h * l - c * k);
-    const double c3 = (d012 + d013) + (d023 + d123);
-    // Laplace expansion over rows (0,1) x rows (2,3)
-    const double c4 = p01 * q23 - p02 * q13 + p03 * q12 + p12 * q03 - p13 * q02 + p23 * q01;
-    double x = c1;
-    if (!(x > 0.0)) return x;                                  // zero / NaN matrix: 1/L is inf / NaN as in the reference
-    for (int it = 0; it < 64; ++it) {
-        const double pv = (((x - c1) * x + c2) * x - c3) * x + c4;
-        const double dv = ((4.0 * x - 3.0 * c1) * x + 2.0 * c2) * x - c3;
-        if (!(pv > 0.0) || !(dv > 0.0)) break;                 // at (or, by rounding, just past) the root
-        const double dx = pv / dv;
-        x -= dx;
-        if (dx <= 1e-15 * x) break;
-    }
-    return x;
-}
-
 template <int KM, int BM>
 __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
 {

@@ -23,11 +23,8 @@
 
 #define SC_FB2 512
 #define SC_NW2 (SC_FB2 / SC_WAVE)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SC_PAIR_VEC_FLOATS 512       // av, bv, cv (128 each) + one zv (64) per wave of the pair
 
-// ---- k-space symmetry, split over a pair of waves (see wave_kspace_symmetry for the maths)
-struct KsGeom { int h, w, ry, rx, ntr, ntc, wp, Fy, Fx; };
 // FFT lengths of a window of half-size r (h = 2 r + 1): fl[0][r] = next_fast_len(2 h + 10) and
 // fl[1][r] = the first EVEN fast length from there (fft.py:95-115 via operator.py:253-288),
 // tabulated in LDS at kernel start so that the constraint phase does not wait on constant loads
@@ -48,190 +45,6 @@ __device__ __forceinline__ KsGeom ks_geom(const SymWindow &s, const unsigned sho
     g.Fy = uniform((int)fl[0][g.ry]);
     g.Fx = uniform((int)fl[1][g.rx]);
     return g;
-}
-
-// Hankel vectors: this wave fills entries q = lane + 64 * half.  Returns s = sin(2 pi dy) / Fy
-// (0 for odd Fy), the coefficient of the rank-1 term.
-__device__ inline float pair_ks_vectors(const KsGeom &g, double dy, double dx, float *vec, int half)
-{
-    float *av = vec, *bv = vec + 128, *cv = vec + 256;
-    // float64 only where the cancellation lives (the arguments and sin/cos); the final quotients
-    // are float32: the kernel entries feed a float32 GEMM
-    double s2x, c2x;
-    const double s2y = sinpi(2.0 * dy);
-    sincospi(2.0 * dx, &s2x, &c2x);
-    const double iFy = 1.0 / g.Fy, iFx = 1.0 / g.Fx;
-    const int q = lane_id() + SC_WAVE * half;
-    float va = 0.f, vb = 0.f, vc = 0.f;
-    if (q <= 2 * (g.h - 1)) {
-        const int n = q - 2 * g.ry;
-        const double tt = (double)n - 2.0 * dy;
-        double sn, cs;
-        sincospi(tt * iFy, &sn, &cs);
-        const double spt = (n & 1) ? s2y : -s2y;
-        va = sn == 0.0 ? 1.f : (float)((g.Fy & 1) ? spt : spt * cs) / (float)(g.Fy * sn);
-    }
-    if (q <= 2 * (g.w - 1)) {
-        const int n = q - 2 * g.rx;
-        const double tt = (double)n - 2.0 * dx;
-        double sn, cs;
-        sincospi(tt * iFx, &sn, &cs);
-        const double spt = (n & 1) ? s2x : -s2x;
-        const double cpt = (n & 1) ? -c2x : c2x;
-        if (sn == 0.0) { vb = 1.f; vc = 0.f; }
-        else {
-            const float r = 1.0f / (float)(g.Fx * sn);
-            vb = (float)(spt * cs) * r; vc = (float)(-(1.0 - cpt) * cs) * r;
-        }
-    }
-    av[q] = va; bv[q] = vb; cv[q] = vc;
-    return (g.Fy & 1) ? 0.f : (float)(s2y * iFy);
-}
-
-// rank-1 term, part 1 (tile reads only): zv[j] = sum_i (-1)^(i-ry) X[i][j]
-__device__ inline void pair_ks_colsums(const Tile &t, const SymWindow &s, const KsGeom &g, float *zv)
-{
-    const int lane = lane_id();
-    float v = 0.f;
-    if (lane < g.w)
-        for (int i = 0; i < g.h; ++i) {
-            const float x = t.m[(s.y0 + i) * t.LW + s.x0 + lane];
-            v += ((i - g.ry) & 1) ? -x : x;
-        }
-    zv[lane] = lane < g.w ? v : 0.f;
-}
-// part 2 (needs the partner's half of cv): zv <- C zv
-__device__ inline void pair_ks_z(const KsGeom &g, const float *cv, float *zv)
-{
-    const int lane = lane_id();
-    wave_sync();
-    float z = 0.f;
-    if (lane < g.w)
-        for (int j2 = 0; j2 < g.w; ++j2) z += cv[lane + j2] * zv[j2];
-    wave_sync();
-    zv[lane] = z;
-    wave_sync();
-}
-
-// GEMM 1: T[:, tc] = Xw . Hankel(bv)[:, tc] for this wave's column tiles tc = half, half + 2.
-// NTR row tiles x NI column tiles are compile-time (the caller switches on the wave-uniform
-// window size): straight-line MFMA chains, no control flow between them.
-template <int NTR, int NI>
-__device__ __forceinline__ void pair_ks_gemm1_impl(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
-                                                   int half, f32x4 (&T)[4][2])
-{
-    const float *bv = vec + 128;
-    const int LW = t.LW, lane = lane_id(), lr = lane & 15, lq = lane >> 4;
-    // rows beyond the window read row h - 1 and columns beyond it column w - 1; both are masked to 0
-    const float *rowp[NTR];
-    bool rowok[NTR];
-#pragma unroll
-    for (int tr = 0; tr < NTR; ++tr) {
-        const int i = (tr << 4) + lr;
-        rowok[tr] = i < g.h;
-        rowp[tr] = t.m + (s.y0 + min(i, g.h - 1)) * LW + s.x0;
-    }
-    const float *bp = bv + (half << 4) + lr + lq;
-    float a[NTR], b[NI], an[NTR], bn[NI];
-    auto fetch = [&](int k0, float (&fa)[NTR], float (&fb)[NI]) {
-        const int k = k0 + lq, kc = min(k, g.w - 1);
-        const bool kok = k < g.w;
-#pragma unroll
-        for (int tr = 0; tr < NTR; ++tr) {
-            const float x = rowp[tr][kc];
-            fa[tr] = (kok && rowok[tr]) ? x : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) fb[i] = bp[k0 + (i << 5)];
-    };
-    fetch(0, a, b);
-    // software pipeline: the operands of step k0 + 4 are in flight while step k0 multiplies
-    for (int k0 = 0; k0 < g.wp; k0 += 4) {
-        fetch(min(k0 + 4, g.wp - 4), an, bn);
-#pragma unroll
-        for (int tr = 0; tr < NTR; ++tr)
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                T[tr][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tr], b[i], T[tr][i], 0, 0, 0);
-#pragma unroll
-        for (int tr = 0; tr < NTR; ++tr) a[tr] = an[tr];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) b[i] = bn[i];
-    }
-}
-
-__device__ inline void pair_ks_gemm1(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
-                                     int half, f32x4 (&T)[4][2])
-{
-#pragma unroll
-    for (int tr = 0; tr < 4; ++tr)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) T[tr][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int ni = half < g.ntc ? (half + 2 < g.ntc ? 2 : 1) : 0;
-    if (ni == 0) return;
-#define SC_G1(NTR_) do { if (ni == 2) pair_ks_gemm1_impl<NTR_, 2>(t, s, g, vec, half, T);          \
-                         else pair_ks_gemm1_impl<NTR_, 1>(t, s, g, vec, half, T); } while (0)
-    switch (g.ntr) { case 1: SC_G1(1); break; case 2: SC_G1(2); break; case 3: SC_G1(3); break; default: SC_G1(4); }
-#undef SC_G1
-}
-
-// GEMM 2 + epilogue in place for this wave's column tiles
-template <int NTR, int NI>
-__device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
-                                                   const float *zv, int half, const f32x4 (&T)[4][2], float sy, bool rank1)
-{
-    float *m = t.m;
-    const float *av = vec;
-    const int LW = t.LW, lane = lane_id(), lr = lane & 15, lq = lane >> 4;
-    // rank-1 term: row parity of (row - ry) depends on r only (16 tr and 4 lq are even)
-    float syr[4], zc[NI];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) syr[r] = rank1 ? (((r - g.ry) & 1) ? -sy : sy) : 0.f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) zc[i] = rank1 ? zv[((half + 2 * i) << 4) + lr] : 0.f;
-#pragma unroll
-    for (int tr = 0; tr < NTR; ++tr) {
-        float areg[NTR][4];
-#pragma unroll
-        for (int tk = 0; tk < NTR; ++tk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) areg[tk][r] = av[(tr << 4) + lr + (tk << 4) + 4 * lq + r];
-        f32x4 acc[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tk = 0; tk < NTR; ++tk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[tk][r], T[tk][i][r], acc[i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int jcol = ((half + 2 * i) << 4) + lr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = (tr << 4) + lq * 4 + r;
-                if (row < g.h && jcol < g.w) {
-                    float *p = &m[(s.y0 + row) * LW + s.x0 + jcol];
-                    const float x = *p;
-                    const float y2 = acc[i][r] + syr[r] * zc[i];
-                    *p = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
-                }
-            }
-        }
-    }
-}
-
-__device__ inline void pair_ks_gemm2(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
-                                     const float *zv, int half, const f32x4 (&T)[4][2], float sy, bool rank1)
-{
-    const int ni = half < g.ntc ? (half + 2 < g.ntc ? 2 : 1) : 0;
-    if (ni == 0) return;
-#define SC_G2(NTR_) do { if (ni == 2) pair_ks_gemm2_impl<NTR_, 2>(t, s, g, vec, zv, half, T, sy, rank1);   \
-                         else pair_ks_gemm2_impl<NTR_, 1>(t, s, g, vec, zv, half, T, sy, rank1); } while (0)
-    switch (g.ntr) { case 1: SC_G2(1); break; case 2: SC_G2(2); break; case 3: SC_G2(3); break; default: SC_G2(4); }
-#undef SC_G2
 }
 
 template <int KM, int BM>

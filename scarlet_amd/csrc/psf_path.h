@@ -234,39 +234,46 @@ __global__ __launch_bounds__(SC_BLOCK) void k_step_psf(PsfArgs a)
     for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
         sed_s[(i / B) * BM + (i % B)] = sed_in[(size_t)s * K * B + i];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int it_new = a.it[s] + 1;
-        const double loss = tot[0];
-        double L_sed, L_morph;
-        if (a.approximate_L) {
+    __shared__ double Lc[2];
+    __shared__ double eigbuf[2][2][64];
+    const int it_new = a.it[s] + 1;                      // len(mse) after the append
+    if (a.approximate_L) {
+        if (threadIdx.x == 0) {
+            // blend.py:189-202: traces of the two Gram matrices, doubled if the loss rose
             double LA = 0, LS = 0;
             int go = 0;
             for (int k = 0; k < K; ++k)
                 for (int k2 = k; k2 < K; ++k2) { if (k2 == k) LA += tot[1 + K * B + go]; ++go; }
             for (int k = 0; k < K; ++k)
                 for (int b = 0; b < B; ++b) LS += (double)sed_s[k * BM + b] * sed_s[k * BM + b];
-            if (it_new > 1 && loss > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { LA *= 2; LS *= 2; }
-            L_sed = LA; L_morph = LS;
-        } else {
-            double *Gm = mat, *ATA = mat + KM * KM;
-            int go = 0;
-            for (int k = 0; k < K; ++k)
-                for (int k2 = k; k2 < K; ++k2) { Gm[k * KM + k2] = Gm[k2 * KM + k] = tot[1 + K * B + go]; ++go; }
-            for (int b = 0; b < B; ++b)
-                for (int b2 = 0; b2 < B; ++b2) {
-                    double r = 0;
-                    for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
-                    ATA[b * BM + b2] = r;
-                }
-            L_sed = jacobi_lambda_max(Gm, K, KM);
-            L_morph = jacobi_lambda_max(ATA, B, BM);
+            if (it_new > 1 && tot[0] > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { LA *= 2; LS *= 2; }
+            Lc[0] = LA; Lc[1] = LS;
         }
-        step_s[0] = 1.0f / (float)L_sed;
-        step_s[1] = 1.0f / (float)L_morph;
+        __syncthreads();
+    } else {
+        // blend.py:205-218: L_sed = lambda_max(S S^T), L_morph = lambda_max(A^T A)
+        double *G = mat, *ATA = mat + KM * KM;
+        for (int i = threadIdx.x; i < K * K; i += SC_BLOCK) {
+            const int k = i / K, k2 = i - k * K, lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
+            G[k * KM + k2] = tot[1 + K * B + lo * K - (lo * (lo - 1)) / 2 + (hi - lo)];
+        }
+        for (int i = threadIdx.x; i < B * B; i += SC_BLOCK) {
+            const int b = i / B, b2 = i - b * B;
+            double r = 0;
+            for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
+            ATA[b * BM + b2] = r;
+        }
+        __syncthreads();
+        block_lipschitz(G, K, KM, ATA, B, BM, eigbuf, Lc);
+    }
+    if (threadIdx.x == 0) {
+        // frame dtype is float32: the reference's L and 1/L are float32 scalars
+        step_s[0] = 1.0f / (float)Lc[0];
+        step_s[1] = 1.0f / (float)Lc[1];
         if (tile == 0) {
-            if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
-            a.lipschitz[2 * s] = L_sed;
-            a.lipschitz[2 * s + 1] = L_morph;
+            if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = tot[0];
+            a.lipschitz[2 * s] = Lc[0];
+            a.lipschitz[2 * s + 1] = Lc[1];
         }
     }
     __syncthreads();
