@@ -110,6 +110,18 @@ __device__ __forceinline__ float block_max_nan(float v, bool isnan_any, float *r
     return bad ? __builtin_nanf("") : r;
 }
 
+// ---------------------------------------------------------------- float4 access to LDS tiles
+__device__ __forceinline__ void lds_store4(float *p, float4 v)
+{   // rows are 8-byte aligned (stride == 2 mod 32 floats): two 8-byte stores
+    reinterpret_cast<float2 *>(p)[0] = make_float2(v.x, v.y);
+    reinterpret_cast<float2 *>(p)[1] = make_float2(v.z, v.w);
+}
+__device__ __forceinline__ float4 lds_load4(const float *p)
+{
+    const float2 a = reinterpret_cast<const float2 *>(p)[0], b = reinterpret_cast<const float2 *>(p)[1];
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+
 // ---------------------------------------------------------------- fast FFT lengths
 // next_fast_len(n) for n < SC_NFL_MAX, filled on the host at first use (scarlet_hip.hip)
 #define SC_NFL_MAX 2304

@@ -628,7 +628,19 @@ __device__ inline void wave_pipeline(const UpdateArgs &a, int c, float *lds_wave
     const int c0 = a.cur[s];
     const int wbuf = a.in_iteration ? 1 - c0 : c0;
     float *gm = a.morph[wbuf] + (size_t)c * HW;
-    for (int i = lane; i < HW; i += SC_WAVE) t.m[(i / W) * t.LW + (i % W)] = gm[i];
+    const bool vec4 = (W & 3) == 0;                     // float4 groups, rows 8-byte aligned in LDS
+    const int gpr = W >> 2, ngroups = HW >> 2;
+    const int dyq = vec4 ? SC_WAVE / gpr : 0, dxq = vec4 ? SC_WAVE - dyq * gpr : 0;    // +64 groups per step
+    const int y0 = vec4 ? lane / gpr : 0, x0 = vec4 ? lane - y0 * gpr : 0;
+    if (vec4) {
+        int y = y0, xq = x0;
+        for (int g = lane; g < ngroups; g += SC_WAVE) {
+            lds_store4(t.m + y * t.LW + (xq << 2), reinterpret_cast<const float4 *>(gm)[g]);
+            y += dyq; xq += dxq;
+            if (xq >= gpr) { xq -= gpr; ++y; }
+        }
+    } else
+        for (int i = lane; i < HW; i += SC_WAVE) t.m[(i / W) * t.LW + (i % W)] = gm[i];
     wave_sync();
     const int it = a.force_it0 ? 0 : a.it[s] + (a.in_iteration ? 1 : 0);
     int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
@@ -647,32 +659,75 @@ __device__ inline void wave_pipeline(const UpdateArgs &a, int c, float *lds_wave
     if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f, &lstop);
     if (lane == 0) { a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
     const float step_morph = 1.0f / (float)a.lipschitz[2 * s + 1];
-    float vmax = -INFINITY;
-    bool anynan = false;
-    for (int i = lane; i < HW; i += SC_WAVE) {
-        float *p = &t.m[(i / W) * t.LW + (i % W)];
-        float v = *p;
-        if (a.l0_thresh >= 0.f && fabsf(v) < a.l0_thresh * step_morph) v = 0.f;
-        if (a.l1_thresh >= 0.f) {
-            const float mag = fabsf(v) - a.l1_thresh * step_morph;
+    const float *gl = a.in_iteration ? a.morph[c0] + (size_t)c * HW : nullptr;
+    const float l0 = a.l0_thresh >= 0.f ? a.l0_thresh * step_morph : -1.f;
+    const float l1 = a.l1_thresh >= 0.f ? a.l1_thresh * step_morph : -1.f;
+    auto sparse_plus = [&](float v, int y, int x) {      // update.py:71-82, 27-32 + the sweep's cut
+        if (l0 >= 0.f && fabsf(v) < l0) v = 0.f;
+        if (l1 >= 0.f) {
+            const float mag = fabsf(v) - l1;
             v = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
         }
-        if (v < 0.f || sweep_level(i / W, i % W, cy, cx) > lstop) v = 0.f;
-        *p = v;
-        anynan |= (v != v);
-        vmax = fmaxf(vmax, v);
-    }
-    float norm = wave_max(vmax);
-    if (__any(anynan)) norm = __builtin_nanf("");
-    if (!(norm > 0.f) || isinf(norm)) stat |= SCARLET_STATUS_NONFINITE;
-    const float *gl = a.in_iteration ? a.morph[c0] + (size_t)c * HW : nullptr;
+        if (v < 0.f || sweep_level(y, x, cy, cx) > lstop) v = 0.f;
+        return v;
+    };
+    float norm;
     double d2 = 0, n2 = 0;
-    for (int i = lane; i < HW; i += SC_WAVE) {
-        const float v = t.m[(i / W) * t.LW + (i % W)] / norm;
-        gm[i] = v;
-        if (gl) { const float d = gl[i] - v; d2 += (double)(d * d); }
-        n2 += (double)(v * v);
+    if (vec4 && a.monotonic) {
+        // One pass in float4 groups.  After the sweep no pixel exceeds the peak pixel (each is capped
+        // by a convex combination of pixels closer to the peak) and the maps above are monotone, so
+        // morph.max() is the processed peak value; a NaN elsewhere shows up in the sums (see below).
+        norm = sparse_plus(t.m[cy * t.LW + cx], cy, cx);
+        const bool regular = norm > 0.f && !isinf(norm);
+        const float rnorm = 1.0f / norm;
+        float d2f = 0.f, n2f = 0.f;
+        int y = y0, xq = x0;
+        for (int g = lane; g < ngroups; g += SC_WAVE) {
+            const float4 v4 = lds_load4(t.m + y * t.LW + (xq << 2));
+            float v[4] = {v4.x, v4.y, v4.z, v4.w}, o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = sparse_plus(v[e], y, (xq << 2) + e);
+                if (regular) { const float q = v[e] * rnorm; o[e] = fmaf(fmaf(-q, norm, v[e]), rnorm, q); }   // v / norm, see fused2.h
+                else o[e] = v[e] / norm;
+            }
+            reinterpret_cast<float4 *>(gm)[g] = make_float4(o[0], o[1], o[2], o[3]);
+            if (gl) {
+                const float4 l = reinterpret_cast<const float4 *>(gl)[g];
+                const float e0 = l.x - o[0], e1 = l.y - o[1], e2 = l.z - o[2], e3 = l.w - o[3];
+                d2f += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+            }
+            n2f += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+            y += dyq; xq += dxq;
+            if (xq >= gpr) { xq -= gpr; ++y; }
+        }
+        if (__any(n2f != n2f) && norm == norm) {
+            // a NaN pixel away from the peak: np.max is NaN and the reference's morph becomes NaN everywhere
+            norm = __builtin_nanf("");
+            for (int g = lane; g < ngroups; g += SC_WAVE) reinterpret_cast<float4 *>(gm)[g] = make_float4(norm, norm, norm, norm);
+            d2f = norm; n2f = norm;
+        }
+        d2 = (double)d2f; n2 = (double)n2f;
+    } else {
+        float vmax = -INFINITY;
+        bool anynan = false;
+        for (int i = lane; i < HW; i += SC_WAVE) {
+            float *p = &t.m[(i / W) * t.LW + (i % W)];
+            const float v = sparse_plus(*p, i / W, i % W);
+            *p = v;
+            anynan |= (v != v);
+            vmax = fmaxf(vmax, v);
+        }
+        norm = wave_max(vmax);
+        if (__any(anynan)) norm = __builtin_nanf("");
+        for (int i = lane; i < HW; i += SC_WAVE) {
+            const float v = t.m[(i / W) * t.LW + (i % W)] / norm;
+            gm[i] = v;
+            if (gl) { const float d = gl[i] - v; d2 += (double)(d * d); }
+            n2 += (double)(v * v);
+        }
     }
+    if (!(norm > 0.f) || isinf(norm)) stat |= SCARLET_STATUS_NONFINITE;
     d2 = wave_sum(d2); n2 = wave_sum(n2);
     // SED: positive, * norm (update.py:27-32,62-65) and its convergence sums
     float *gs = a.sed[wbuf] + (size_t)c * B;

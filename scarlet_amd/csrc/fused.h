@@ -43,17 +43,6 @@ struct FusedArgs {
     long long *stamps;               // NULL, or [S][16] shader-clock stamps (diagnostics only)
 };
 
-__device__ __forceinline__ void lds_store4(float *p, float4 v)
-{   // rows are 8-byte aligned (stride == 2 mod 32 floats): two 8-byte stores
-    reinterpret_cast<float2 *>(p)[0] = make_float2(v.x, v.y);
-    reinterpret_cast<float2 *>(p)[1] = make_float2(v.z, v.w);
-}
-__device__ __forceinline__ float4 lds_load4(const float *p)
-{
-    const float2 a = reinterpret_cast<const float2 *>(p)[0], b = reinterpret_cast<const float2 *>(p)[1];
-    return make_float4(a.x, a.y, b.x, b.y);
-}
-
 template <int KM, int BM>
 __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)
 {
