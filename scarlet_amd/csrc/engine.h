@@ -508,8 +508,20 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
     const int c0 = a.cur[s];
     const int wbuf = a.in_iteration ? 1 - c0 : c0;
     float *gm = a.morph[wbuf] + (size_t)c * HW;
+    // float4 groups walked without divisions: +256 groups per step
+    const bool vec4 = (W & 3) == 0;
+    const int gpr = W >> 2, ngroups = HW >> 2;
+    const int dyq = vec4 ? SC_BLOCK / gpr : 0, dxq = vec4 ? SC_BLOCK - dyq * gpr : 0;
+    const int y0 = vec4 ? (int)threadIdx.x / gpr : 0, x0 = vec4 ? (int)threadIdx.x - y0 * gpr : 0;
     if (GT) t.m = gm;
-    else
+    else if (vec4) {
+        int y = y0, xq = x0;
+        for (int g = threadIdx.x; g < ngroups; g += SC_BLOCK) {
+            lds_store4(t.m + y * t.LW + (xq << 2), reinterpret_cast<const float4 *>(gm)[g]);
+            y += dyq; xq += dxq;
+            if (xq >= gpr) { xq -= gpr; ++y; }
+        }
+    } else
         for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
             const int y = i / W, x = i - y * W;
             t.m[y * t.LW + x] = gm[i];
@@ -541,34 +553,81 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
     // sparse_l0 / sparse_l1 (update.py:71-82; config 5), positive (update.py:27-32),
     // normalized('morph_max') (update.py:62-65)
     const float step_morph = 1.0f / (float)a.lipschitz[2 * s + 1];
-    float vmax = -INFINITY;
-    bool anynan = false;
-    for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
-        const int y = i / W, x = i - y * W;
-        float v = t.m[y * t.LW + x];
-        if (a.l0_thresh >= 0.f && fabsf(v) < a.l0_thresh * step_morph) v = 0.f;
-        if (a.l1_thresh >= 0.f) {
-            const float mag = fabsf(v) - a.l1_thresh * step_morph;
+    const float *gl = a.in_iteration ? a.morph[c0] + (size_t)c * HW : nullptr;
+    const float l0 = a.l0_thresh >= 0.f ? a.l0_thresh * step_morph : -1.f;
+    const float l1 = a.l1_thresh >= 0.f ? a.l1_thresh * step_morph : -1.f;
+    auto sparse_plus = [&](float v, int y, int x) {      // update.py:71-82, 27-32 + the sweep's cut
+        if (l0 >= 0.f && fabsf(v) < l0) v = 0.f;
+        if (l1 >= 0.f) {
+            const float mag = fabsf(v) - l1;
             v = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
         }
         if (v < 0.f || sweep_level(y, x, cy, cx) > lstop) v = 0.f;
-        t.m[y * t.LW + x] = v;
-        anynan |= (v != v);
-        vmax = fmaxf(vmax, v);
-    }
-    const float norm = block_max_nan(vmax, anynan, redf);
-    if (threadIdx.x == 0 && (!(norm > 0.f) || isinf(norm))) stat |= SCARLET_STATUS_NONFINITE;
-    const float *gl = a.in_iteration ? a.morph[c0] + (size_t)c * HW : nullptr;
+        return v;
+    };
+    float norm;
     double d2 = 0, n2 = 0;
-    for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
-        const int y = i / W, x = i - y * W;
-        const float v = t.m[y * t.LW + x] / norm;
-        gm[i] = v;
-        if (gl) { const float d = gl[i] - v; d2 += (double)(d * d); }
-        n2 += (double)(v * v);
+    if (vec4 && a.monotonic) {
+        // one pass in float4 groups; morph.max() is the processed peak pixel after a sweep (see
+        // wave_pipeline below); a NaN elsewhere shows up in the sums
+        __syncthreads();
+        norm = sparse_plus(t.m[cy * t.LW + cx], cy, cx);
+        __syncthreads();                                 // (in place when GT: read the peak before it is normalised)
+        const bool regular = norm > 0.f && !isinf(norm);
+        const float rnorm = 1.0f / norm;
+        float d2f = 0.f, n2f = 0.f;
+        int y = y0, xq = x0;
+        for (int g = threadIdx.x; g < ngroups; g += SC_BLOCK) {
+            const float *p = t.m + y * t.LW + (xq << 2);
+            const float4 v4 = GT ? *reinterpret_cast<const float4 *>(p) : lds_load4(p);
+            float v[4] = {v4.x, v4.y, v4.z, v4.w}, o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = sparse_plus(v[e], y, (xq << 2) + e);
+                if (regular) { const float q = v[e] * rnorm; o[e] = fmaf(fmaf(-q, norm, v[e]), rnorm, q); }   // v / norm, see fused2.h
+                else o[e] = v[e] / norm;
+            }
+            reinterpret_cast<float4 *>(gm)[g] = make_float4(o[0], o[1], o[2], o[3]);
+            if (gl) {
+                const float4 l = reinterpret_cast<const float4 *>(gl)[g];
+                const float e0 = l.x - o[0], e1 = l.y - o[1], e2 = l.z - o[2], e3 = l.w - o[3];
+                d2f += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+            }
+            n2f += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+            y += dyq; xq += dxq;
+            if (xq >= gpr) { xq -= gpr; ++y; }
+        }
+        d2 = (double)d2f; n2 = (double)n2f;
+        d2 = block_sum(d2, red);
+        n2 = block_sum(n2, red);
+        if (n2 != n2 && norm == norm) {
+            // a NaN pixel away from the peak: np.max is NaN and the reference's morph becomes NaN everywhere
+            norm = __builtin_nanf("");
+            for (int g = threadIdx.x; g < ngroups; g += SC_BLOCK) reinterpret_cast<float4 *>(gm)[g] = make_float4(norm, norm, norm, norm);
+            d2 = norm;
+        }
+    } else {
+        float vmax = -INFINITY;
+        bool anynan = false;
+        for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
+            const int y = i / W, x = i - y * W;
+            const float v = sparse_plus(t.m[y * t.LW + x], y, x);
+            t.m[y * t.LW + x] = v;
+            anynan |= (v != v);
+            vmax = fmaxf(vmax, v);
+        }
+        norm = block_max_nan(vmax, anynan, redf);
+        for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
+            const int y = i / W, x = i - y * W;
+            const float v = t.m[y * t.LW + x] / norm;
+            gm[i] = v;
+            if (gl) { const float d = gl[i] - v; d2 += (double)(d * d); }
+            n2 += (double)(v * v);
+        }
+        d2 = block_sum(d2, red);
+        n2 = block_sum(n2, red);
     }
-    d2 = block_sum(d2, red);
-    n2 = block_sum(n2, red);
+    if (threadIdx.x == 0 && (!(norm > 0.f) || isinf(norm))) stat |= SCARLET_STATUS_NONFINITE;
     if (threadIdx.x == 0) {
         float *gs = a.sed[wbuf] + (size_t)c * B;
         const float *gsl = a.in_iteration ? a.sed[c0] + (size_t)c * B : nullptr;
