@@ -1,8 +1,10 @@
 // fused.h -- one kernel per proximal-gradient iteration, one workgroup per scene.
 //
-// When the K morphologies of a scene fit in LDS (K * H * (W+2) * 4 B <= ~140 KiB, H, W <= 64,
-// W % 4 == 0) the whole iteration of Blend.fit (blend.py:79-102) runs in one launch with the
-// morphologies resident in LDS between the gradient step and the constraints:
+// For K <= 4 components on frames up to 64 x 64 (W % 4 == 0) the whole iteration of Blend.fit
+// (blend.py:79-102) runs in one launch with the morphologies resident in LDS between the gradient
+// step and the constraints.  This file holds the four-wave kernel k_iterate<4, BM> (one wave per
+// component; used for 5 < B <= 8) and the pieces shared with the eight-wave kernel of fused2.h
+// (K <= 4, B <= 5: the headline workload).  Phases:
 //
 //   phase 0  ALL global loads of the iteration are issued first (morph tiles and images,
 //            16 B/lane); morph tiles -> LDS, morph Gram S S^T on the fly            [a6]
@@ -15,10 +17,10 @@
 //            writes the result to the other HBM buffer                              [a8-a17]
 //   phase 3  convergence flags, it/cur bookkeeping                                  [a18]
 //
-// HBM traffic per scene-iteration = images + morph read + morph write (+ a second,
-// L2-resident read of the previous morph for the convergence sums) -- the algorithmic
-// bytes of SURVEY.md 8d.  The unfused kernels of engine.h remain the general path
-// (larger images, approximate_L).
+// HBM traffic per scene-iteration = images + morph read + morph write (+ a second read of the
+// previous morph for the convergence sums) -- the algorithmic bytes of SURVEY.md 8d plus that
+// re-read.  The unfused kernels of engine.h remain the general path (K > 4, larger frames,
+// approximate_L, PSF).
 #pragma once
 #include <type_traits>
 #include "common.h"

@@ -1,6 +1,6 @@
 // wave_ops.h -- the constraint pipeline with ONE 64-lane wavefront per component.
 //
-// Why wave-level: the radial sweep is a chain of ~100-190 dependent levels.  With a
+// Why wave-level: the radial sweep is a chain of up to ~190 dependent levels (~40 with the early exit).  With a
 // 256-thread workgroup per component (prox_ops.h) three of the four waves idle through the
 // small levels and every level pays an s_barrier; with one wave per component there are
 // no barriers at all (LDS operations of one wave complete in order), four components
