@@ -649,9 +649,7 @@ static float *ws_gscratch(const scarlet_batch *b)
     return (float *)((char *)ws_resid(b) + resid);
 }
 
-static thread_local int g_raw_gradient = 0;      // set by scarlet_backward_gradients around scarlet_backward_step
-
-static GradArgs grad_args(const scarlet_batch *b, int approximate_L)
+static GradArgs grad_args(const scarlet_batch *b, int approximate_L, int raw_gradient = 0)
 {
     GradArgs a;
     a.S = b->S; a.K = b->K; a.B = b->B; a.HW = b->H * b->W; a.T = n_tiles(b);
@@ -659,7 +657,7 @@ static GradArgs grad_args(const scarlet_batch *b, int approximate_L)
     a.sed[0] = b->sed[0]; a.sed[1] = b->sed[1]; a.morph[0] = b->morph[0]; a.morph[1] = b->morph[1];
     a.cur = b->cur; a.fix_sed = b->fix_sed; a.fix_morph = b->fix_morph;
     a.partials = ws_partials(b); a.lipschitz = b->lipschitz; a.mse = b->mse; a.mse_capacity = b->mse_capacity;
-    a.it = b->it; a.active = b->active; a.approximate_L = approximate_L; a.raw_gradient = g_raw_gradient;
+    a.it = b->it; a.active = b->active; a.approximate_L = approximate_L; a.raw_gradient = raw_gradient;
     return a;
 }
 
@@ -720,7 +718,7 @@ extern "C" int scarlet_batch_prepare_psf(scarlet_batch *b, void *stream)
     return SCARLET_OK;
 }
 
-static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
+static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradient, void *stream)
 {
     const PsfGeom g = psf_geom(b->H, b->W, b->psf_h, b->psf_w);
     const PsfLayout l = psf_layout(b);
@@ -735,7 +733,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
     a.khat = (const float2 *)((char *)b->workspace + l.khat);
     a.partials = ws_partials(b); a.loss_part = (double *)((char *)b->workspace + l.loss);
     a.lipschitz = b->lipschitz; a.mse = b->mse; a.mse_capacity = b->mse_capacity;
-    a.it = b->it; a.active = b->active; a.approximate_L = approximate_L; a.raw_gradient = g_raw_gradient;
+    a.it = b->it; a.active = b->active; a.approximate_L = approximate_L; a.raw_gradient = raw_gradient;
     const int planes = b->S * b->B;
     const int plane_elems = g.Fy * g.Fxh;
     const float scale = 1.0f / ((float)g.Fy * (float)g.Fx);
@@ -758,7 +756,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, void *stream)
     dim3 grid(a.T, a.S);
     if (b->K > SC_KMAX) {
         // many components: G is cropped out of the FFT buffers once, then the chunked passes of bigk.h
-        GradArgs ga = grad_args(b, approximate_L);
+        GradArgs ga = grad_args(b, approximate_L, raw_gradient);
         float *resid = ws_resid(b);
         const int nch = (b->K + SC_CHUNK - 1) / SC_CHUNK;
         prof_start(0, st);
@@ -863,12 +861,13 @@ extern "C" int scarlet_convolve_same(const float *model, int n, int H, int W, co
     return SCARLET_OK;
 }
 
-extern "C" int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *stream)
+// raw_gradient = 0: buffer 1-cur receives the stepped factors; 1: the gradients themselves
+static int backward_impl(scarlet_batch *b, int approximate_L, int raw_gradient, void *stream)
 {
     int rc = check_batch(b);
     if (rc) return rc;
-    if (b->diff_kernel) return backward_step_psf(b, approximate_L, stream);
-    GradArgs a = grad_args(b, approximate_L);
+    if (b->diff_kernel) return backward_step_psf(b, approximate_L, raw_gradient, stream);
+    GradArgs a = grad_args(b, approximate_L, raw_gradient);
     dim3 grid(a.T, a.S);
     hipStream_t st = (hipStream_t)stream;
     if (b->K > SC_KMAX) {
@@ -903,12 +902,14 @@ extern "C" int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *
     return SCARLET_OK;
 }
 
+extern "C" int scarlet_backward_step(scarlet_batch *b, int approximate_L, void *stream)
+{
+    return backward_impl(b, approximate_L, 0, stream);
+}
+
 extern "C" int scarlet_backward_gradients(scarlet_batch *b, int approximate_L, void *stream)
 {
-    g_raw_gradient = 1;
-    const int rc = scarlet_backward_step(b, approximate_L, stream);
-    g_raw_gradient = 0;
-    return rc;
+    return backward_impl(b, approximate_L, 1, stream);
 }
 
 static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void *stream)
