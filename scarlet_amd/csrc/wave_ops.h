@@ -416,43 +416,61 @@ template <int NTR, int NI>
 __device__ __forceinline__ void pair_ks_gemm1_impl(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
                                                    int half, f32x4 (&T)[4][2])
 {
+    // The sum over k is taken in groups of 16: in group k0 the j-th MFMA (j = 0..3) lets lane
+    // (lr, lq) supply k = k0 + 4 lq + j, so that every lane reads FOUR CONSECUTIVE floats of its X row
+    // and of the Hankel vector per group (one address, four immediate offsets) instead of one float
+    // per step, and a whole group is in flight while the previous one multiplies.
     const float *bv = vec + 128;
     const int LW = t.LW, lane = lane_id(), lr = lane & 15, lq = lane >> 4;
-    // rows beyond the window read row h - 1 and columns beyond it column w - 1; both are masked to 0
-    const float *rowp[NTR];
-    bool rowok[NTR];
+    const float *rowp[NTR];                     // rows beyond the window read row h - 1 (zeroed at the end)
 #pragma unroll
-    for (int tr = 0; tr < NTR; ++tr) {
-        const int i = (tr << 4) + lr;
-        rowok[tr] = i < g.h;
-        rowp[tr] = t.m + (s.y0 + min(i, g.h - 1)) * LW + s.x0;
-    }
-    const float *bp = bv + (half << 4) + lr + lq;
-    float a[NTR], b[NI], an[NTR], bn[NI];
-    auto fetch = [&](int k0, float (&fa)[NTR], float (&fb)[NI]) {
-        const int k = k0 + lq, kc = min(k, g.w - 1);
-        const bool kok = k < g.w;
-#pragma unroll
-        for (int tr = 0; tr < NTR; ++tr) {
-            const float x = rowp[tr][kc];
-            fa[tr] = (kok && rowok[tr]) ? x : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) fb[i] = bp[k0 + (i << 5)];
-    };
-    fetch(0, a, b);
-    // software pipeline: the operands of step k0 + 4 are in flight while step k0 multiplies
-    for (int k0 = 0; k0 < g.wp; k0 += 4) {
-        fetch(min(k0 + 4, g.wp - 4), an, bn);
+    for (int tr = 0; tr < NTR; ++tr)
+        rowp[tr] = t.m + (s.y0 + min((tr << 4) + lr, g.h - 1)) * LW + s.x0 + 4 * lq;
+    const float *bp = bv + (half << 4) + lr + 4 * lq;
+    struct Ops { float a[NTR][4], b[NI][4]; };
+    auto fetch = [&](int k0) {
+        Ops o;
+        // columns beyond the window (only in the last group: wp - w < 16) must count as zero
+        const bool last = k0 + 16 > g.w;
 #pragma unroll
         for (int tr = 0; tr < NTR; ++tr)
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
-                T[tr][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tr], b[i], T[tr][i], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const float x = rowp[tr][k0 + j];
+                o.a[tr][j] = (last && k0 + 4 * lq + j >= g.w) ? 0.f : x;
+            }
 #pragma unroll
-        for (int tr = 0; tr < NTR; ++tr) a[tr] = an[tr];
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) b[i] = bn[i];
+            for (int j = 0; j < 4; ++j) o.b[i][j] = bp[k0 + (i << 5) + j];
+        return o;
+    };
+    auto multiply = [&](const Ops &o) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tr = 0; tr < NTR; ++tr)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    T[tr][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[tr][j], o.b[i][j], T[tr][i], 0, 0, 0);
+    };
+    // two groups per trip, ping-pong operand sets (no register copies)
+    Ops o0 = fetch(0);
+    for (int k0 = 0; k0 < g.wp; k0 += 32) {
+        const Ops o1 = fetch(min(k0 + 16, g.wp - 16));
+        multiply(o0);
+        if (k0 + 16 < g.wp) {
+            o0 = fetch(min(k0 + 32, g.wp - 16));
+            multiply(o1);
+        }
+    }
+    // rows of T beyond the window (last row tile only) came from the clamped row pointer: zero them
+    const int rbase = ((NTR - 1) << 4) + 4 * lq;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const f32x4 v = T[NTR - 1][i];
+        T[NTR - 1][i] = (f32x4){rbase < g.h ? v[0] : 0.f, rbase + 1 < g.h ? v[1] : 0.f,
+                                rbase + 2 < g.h ? v[2] : 0.f, rbase + 3 < g.h ? v[3] : 0.f};
     }
 }
 
