@@ -503,13 +503,30 @@ __device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindo
     for (int r = 0; r < 4; ++r) syr[r] = rank1 ? (((r - g.ry) & 1) ? -sy : sy) : 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) zc[i] = rank1 ? zv[((half + 2 * i) << 4) + lr] : 0.f;
+    // Hankel operand: A[i][k] = av[i + k] depends on tr + tk only -- the 2 NTR - 1 distinct 16 x 4
+    // slices are read once, up front
+    float ah[2 * NTR - 1][4];
+#pragma unroll
+    for (int d = 0; d < 2 * NTR - 1; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ah[d][r] = av[(d << 4) + lr + 4 * lq + r];
 #pragma unroll
     for (int tr = 0; tr < NTR; ++tr) {
-        float areg[NTR][4];
+        // the pixels this lane will combine with: requested before the MFMA chain, used after it
+        float xin[NI][4];
+        float *pp[NI][4];
+        bool ok[NI][4];
 #pragma unroll
-        for (int tk = 0; tk < NTR; ++tk)
+        for (int i = 0; i < NI; ++i) {
+            const int jcol = ((half + 2 * i) << 4) + lr;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) areg[tk][r] = av[(tr << 4) + lr + (tk << 4) + 4 * lq + r];
+            for (int r = 0; r < 4; ++r) {
+                const int row = (tr << 4) + lq * 4 + r;
+                ok[i][r] = row < g.h && jcol < g.w;
+                pp[i][r] = &m[(s.y0 + (ok[i][r] ? row : 0)) * LW + s.x0 + (ok[i][r] ? jcol : 0)];
+                xin[i][r] = *pp[i][r];
+            }
+        }
         f32x4 acc[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -519,21 +536,15 @@ __device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindo
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[tk][r], T[tk][i][r], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[tr + tk][r], T[tk][i][r], acc[i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int jcol = ((half + 2 * i) << 4) + lr;
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = (tr << 4) + lq * 4 + r;
-                if (row < g.h && jcol < g.w) {
-                    float *p = &m[(s.y0 + row) * LW + s.x0 + jcol];
-                    const float x = *p;
-                    const float y2 = acc[i][r] + syr[r] * zc[i];
-                    *p = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
-                }
+                const float x = xin[i][r];
+                const float y2 = acc[i][r] + syr[r] * zc[i];
+                if (ok[i][r]) *pp[i][r] = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
             }
-        }
     }
 }
 
