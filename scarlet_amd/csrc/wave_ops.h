@@ -505,6 +505,7 @@ __device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindo
     for (int i = 0; i < NI; ++i) zc[i] = rank1 ? zv[((half + 2 * i) << 4) + lr] : 0.f;
     // Hankel operand: A[i][k] = av[i + k] depends on tr + tk only -- the 2 NTR - 1 distinct 16 x 4
     // slices are read once, up front
+    float *dummy = const_cast<float *>(vec) + 128 + lane;
     float ah[2 * NTR - 1][4];
 #pragma unroll
     for (int d = 0; d < 2 * NTR - 1; ++d)
@@ -523,7 +524,9 @@ __device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindo
             for (int r = 0; r < 4; ++r) {
                 const int row = (tr << 4) + lq * 4 + r;
                 ok[i][r] = row < g.h && jcol < g.w;
-                pp[i][r] = &m[(s.y0 + (ok[i][r] ? row : 0)) * LW + s.x0 + (ok[i][r] ? jcol : 0)];
+                // lanes outside the window combine a dummy slot (the B vector is dead after GEMM 1):
+                // no branches between the MFMA chains
+                pp[i][r] = ok[i][r] ? &m[(s.y0 + row) * LW + s.x0 + jcol] : dummy;
                 xin[i][r] = *pp[i][r];
             }
         }
@@ -543,7 +546,7 @@ __device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindo
             for (int r = 0; r < 4; ++r) {
                 const float x = xin[i][r];
                 const float y2 = acc[i][r] + syr[r] * zc[i];
-                if (ok[i][r]) *pp[i][r] = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
+                *pp[i][r] = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
             }
     }
 }
