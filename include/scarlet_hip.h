@@ -141,6 +141,25 @@ int scarlet_prox_soft(float *x, int64_t count, float thresh_times_step, void *st
 /* update.normalized (update.py:35-68) for n components: sed [n][B], morph [n][H*W]. */
 int scarlet_normalize(float *sed, float *morph, int n, int B, int HW, int type, void *stream);
 
+/* measurement.threshold (measurement.py:97-112), device part, for n arrays of `count` floats:
+ * scarlet_log_range: out [n][3] float64 = {number of positive pixels, min, max of their log10};
+ * scarlet_log_hist: np.histogram of log10(positive pixels) over nbins[i] <= 50 equal bins whose
+ * edges [n][51] float64 the caller tabulates (np.linspace, as numpy does); hist [n][50] int32.
+ * The caller picks the lower edge of the last empty bin (measurement.py:107-112). */
+int scarlet_log_range(const float *x, int n, int64_t count, double *out, void *stream);
+int scarlet_log_hist(const float *x, int n, int64_t count, const double *edges,
+                     const int32_t *nbins, int32_t *hist, void *stream);
+/* update.threshold (update.py:98): x[x < thresh] = 0. */
+int scarlet_cut_below(float *x, int64_t count, double thresh, void *stream);
+/* bbox.trim (bbox.py:174-193) for n planes [H][W]: box [n][4] int32 = {bottom, top, left, right} of
+ * x > min_value (inclusive bounds); {H, -1, W, -1} when no pixel qualifies. */
+int scarlet_trim(const float *x, int n, int H, int W, float min_value, int32_t *box, void *stream);
+/* interpolation.fft_resample (interpolation.py:408-448) as used by update.translation
+ * (update.py:159-167), n planes [H][W], out of place: separable taps [n][2][8] float64 (ky, kx:
+ * ny / nx of them used), first tap positions win0 [n][2] int32 (the kernels' window[0]). */
+int scarlet_resample(const float *in, float *out, int n, int H, int W, const double *taps,
+                     const int32_t *win0, int ny, int nx, void *stream);
+
 /* apply_filter on device (operators_pybind11.cc:53-70), one image. */
 int scarlet_apply_filter(const float *image, int H, int W, const float *values,
                          const int32_t *y_start, const int32_t *y_end, const int32_t *x_start,

@@ -368,10 +368,98 @@ def gen_fit_extras(sc):
     save("fit_extras", **out)
 
 
+def gen_fit_extras2(sc):
+    """approximate_L with two observations (blend.py:189-201, 219-220): the crude Lipschitz bound,
+    doubled when the summed loss rose, times the number of observations."""
+    out = {}
+    bg = np.ones(5) * 0.1
+    scn = synth.make_scene(7)
+    images = scn["images"]
+    ch = list("grizy")
+    frame = sc.Frame(images.shape, dtype=np.float32, channels=ch)
+    full = sc.Observation(images, channels=ch).match(frame)
+    cen = [tuple(int(v) for v in p) for p in scn["centers"]]
+    srcs = [sc.ExtendedSource(frame, p, full, bg) for p in cen]
+    noise = np.random.RandomState(5).normal(0, 0.1, images.shape).astype(np.float32)
+    obs = [sc.Observation(images, channels=ch).match(frame),
+           sc.Observation(images + noise, channels=ch).match(frame)]
+    blend = sc.Blend(srcs, obs)
+    blend.fit(12, e_rel=0, approximate_L=True)
+    out["images2"] = images + noise
+    out["sed"] = np.array([c.sed for c in blend.components])
+    out["morph"] = np.array([c.morph for c in blend.components])
+    out["mse"] = np.array(blend.mse)
+    out["center"] = np.array([c.pixel_center for c in blend.components]).astype(np.int64)
+    save("fit_extras2", **out)
+
+
+def gen_thresh_translate(sc):
+    """update.threshold / measurement.threshold (log-histogram noise cut) and update.translation
+    (Lanczos resampling by component.shift): SURVEY.md 8f rank 3, off the default pipeline."""
+    upd, meas = sc.update, sc.measurement
+    out = {}
+    # the reference's own test case (tests/test_update.py:98-117) plus three synthetic morphologies
+    np.random.seed(0)
+    noise = np.random.rand(21, 21) * 2
+    signal = np.zeros(noise.shape)
+    signal[7:14, 7:14] = sc.psf.generate_psf_image(sc.psf.gaussian, (21, 21), normalize=False,
+                                                   amplitude=10, sigma=3)[7:14, 7:14].image
+    morphs = [signal + noise]
+    rng = np.random.RandomState(23)
+    y, x = np.mgrid[:64, :64]
+    g = np.exp(-((y - 30.) ** 2 + (x - 35.) ** 2) / (2 * 3. ** 2))
+    morphs.append(g + 1e-4 * rng.rand(64, 64))              # > 500 positive pixels: 50 bins
+    m = g.copy(); m[g < 1e-3] = 0
+    morphs.append(m)                                        # few positive pixels: size/10 bins
+    m = np.zeros((16, 16)); m[5:8, 6:9] = rng.rand(3, 3)
+    morphs.append(m)                                        # < 20 positive pixels: one bin, no cut
+    morphs.append(rng.rand(40, 32) - 0.3)                   # negatives present
+    for n, morph in enumerate(morphs):
+        for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+            mm = morph.astype(dt)
+            frame = sc.Frame((3,) + mm.shape, dtype=dt)
+            c = sc.Component(frame, np.arange(3).astype(dt), mm.copy())
+            thresh, bins = meas.threshold(c.morph)
+            upd.threshold(c)
+            b = c.bboxes["thresh"]
+            out["thr_in%d_%s" % (n, tag)] = mm
+            out["thr_value%d_%s" % (n, tag)] = np.array([float(thresh), float(bins)])
+            out["thr_out%d_%s" % (n, tag)] = c.morph.copy()
+            out["thr_box%d_%s" % (n, tag)] = np.array([b.bottom, b.top, b.left, b.right])
+    out["thr_n"] = np.array(len(morphs))
+    # translation
+    shifts = [(0.217, -0.026), (-0.691, 0.321), (0.5, 0.5), (-0.3, 0.0), (0.0, 0.0)]
+    img = rng.rand(31, 27) - 0.2
+    for n, sh in enumerate(shifts):
+        for direction in (1, -1):
+            frame = sc.Frame((3,) + img.shape, dtype=np.float64)
+            c = sc.Component(frame, np.arange(3.), img.copy())
+            c.shift = np.array(sh)
+            upd.translation(c, direction=direction)
+            out["tr_out%d_%d" % (n, direction)] = c.morph.copy()
+    out["tr_in"] = img
+    out["tr_shifts"] = np.array(shifts)
+    # interpolation.fft_resample with the bilinear kernel (the case tests/test_interpolation.py:365-393 pins)
+    _img = np.arange(36).reshape(6, 6)
+    im = np.zeros((11, 11)); im[2:8, 2:8] = _img
+    out["bil_in"] = im
+    out["bil_out0"] = sc.interpolation.fft_resample(im, .217, -.026, kernel=sc.interpolation.bilinear)
+    out["bil_out1"] = sc.interpolation.fft_resample(im, -.691, .321, kernel=sc.interpolation.bilinear)
+    save("thresh_translate", **out)
+
+
 def main():
     sc = load_reference()
     import scarlet.cache
     sc.cache = scarlet.cache
+    if len(sys.argv) > 1 and sys.argv[1] == "thresh":
+        import scarlet.interpolation
+        sc.interpolation = scarlet.interpolation
+        gen_thresh_translate(sc)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "extras2":
+        gen_fit_extras2(sc)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "extras":
         gen_fit_extras(sc)
         return
@@ -384,6 +472,10 @@ def main():
     gen_fit_hsc(sc)
     gen_fit_synth(sc)
     gen_fit_extras(sc)
+    import scarlet.interpolation
+    sc.interpolation = scarlet.interpolation
+    gen_thresh_translate(sc)
+    gen_fit_extras2(sc)
 
 
 if __name__ == "__main__":

@@ -828,3 +828,85 @@ def trim_bounds(X, min_value=0):
 def flux_at_edge(X, min_value=0):
     """bbox.flux_at_edge (bbox.py:196-210)."""
     return bool(max(X[:, 0].max(), X[:, -1].max(), X[0].max(), X[-1].max()) > min_value)
+
+
+# --------------------------------------------------------------------------- measurement.threshold / update.threshold
+def threshold(morph):
+    """measurement.threshold (measurement.py:97-112): noise cut from the histogram of
+    log10(positive pixels).  50 bins, or size/10 when fewer than 500 pixels are positive
+    (one bin -> no cut); the cut is the lower edge of the LAST empty bin, 0 if none is empty.
+    Returns (thresh, bins)."""
+    pos = morph[morph > 0]
+    bins = 50
+    if pos.size < 500:
+        bins = max(int(pos.size / 10), 1)
+        if bins == 1:
+            return 0, bins
+    hist, edges = np.histogram(np.log10(pos).reshape(-1), bins)
+    empty = np.where(hist == 0)[0]
+    if len(empty) == 0:
+        return 0, bins
+    return 10 ** edges[empty[-1]], bins
+
+
+def update_threshold(morph):
+    """update.threshold (update.py:85-103): zero below the cut (in place), return the cut and
+    the tight box (bottom, top, left, right) of what is left (bbox.trim)."""
+    thresh, _ = threshold(morph)
+    morph[morph < thresh] = 0
+    return thresh, trim_bounds(morph)
+
+
+# --------------------------------------------------------------------------- interpolation.py / update.translation
+def lanczos(dx, a=3):
+    """interpolation.lanczos (interpolation.py:233-252): taps at floor(dx) + (-a+1 .. a)."""
+    if np.abs(dx) > 1:
+        raise ValueError("The fractional shift dx must be between -1 and 1")
+    window = np.arange(-a + 1, a + 1) + np.floor(dx)
+    return np.sinc(dx - window) * np.sinc((dx - window) / a), window.astype(int)
+
+
+def bilinear(dx):
+    """interpolation.bilinear (interpolation.py:139-165)."""
+    if np.abs(dx) > 1:
+        raise ValueError("The fractional shift dx must be between -1 and 1")
+    if dx >= 0:
+        return np.array([1 - dx, dx]), np.arange(2)
+    return np.array([-dx, 1 + dx]), np.array([-1, 0])
+
+
+def _project(image, shape, yx0=None):
+    """interpolation.project_image (interpolation.py:6-84): place `image` in zeros(shape) with its
+    first pixel at shape//2 + yx0 (yx0 = -(image.shape//2) when None), clipped at the borders."""
+    out = np.zeros(shape)
+    if yx0 is None:
+        yx0 = (-(image.shape[0] // 2), -(image.shape[1] // 2))
+    sl_out, sl_in = [], []
+    for n, i, o in zip(shape, image.shape, yx0):
+        lo = o + (n >> 1)
+        hi = lo + i
+        sl_out.append(slice(max(0, lo), min(n, hi)))
+        sl_in.append(slice(max(0, -lo), max(n - lo, -hi)))
+    out[tuple(sl_out)] = image[tuple(sl_in)]
+    return out
+
+
+def fft_resample(img, dy, dx, kernel=lanczos):
+    """interpolation.fft_resample (interpolation.py:408-448) with fft_convolve (:114-136):
+    circular convolution of the zero-padded image with the separable kernel, both ifftshift-ed,
+    the real part fftshift-ed back and cropped to the image."""
+    ky, ywin = kernel(dy)
+    kx, xwin = kernel(dx)
+    k2 = np.outer(ky, kx)
+    shape = (img.shape[0] + k2.shape[0] + 3, img.shape[1] + k2.shape[1] + 3)
+    K = _project(k2, shape, (ywin[0], xwin[0]))
+    I = _project(img, shape)
+    prod = np.fft.fft2(np.fft.ifftshift(I)) * np.fft.fft2(np.fft.ifftshift(K))
+    res = np.fft.fftshift(np.real(np.fft.ifft2(prod)))
+    return _project(res, img.shape)
+
+
+def update_translation(morph, shift, direction=1):
+    """update.translation (update.py:159-167): morph[:] = fft_resample(morph, dy, dx), Lanczos-3."""
+    morph[:] = fft_resample(morph, shift[0] * direction, shift[1] * direction)
+    return morph

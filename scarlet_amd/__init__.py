@@ -9,6 +9,7 @@ from . import operator
 from . import psf
 from . import fft
 from . import measurement
+from . import interpolation
 from . import update as _update_module
 from .bbox import Box, trim, flux_at_edge
 from .cache import Cache

@@ -72,6 +72,11 @@ _SIGNATURES = {
     "scarlet_prox_hard": (c_int, [_P, c_int64, c_float, _P]),
     "scarlet_prox_soft": (c_int, [_P, c_int64, c_float, _P]),
     "scarlet_normalize": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "scarlet_log_range": (c_int, [_P, c_int, c_int64, _P, _P]),
+    "scarlet_log_hist": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P]),
+    "scarlet_cut_below": (c_int, [_P, c_int64, c_double, _P]),
+    "scarlet_trim": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P]),
+    "scarlet_resample": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
     "scarlet_apply_filter": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P]),
     "scarlet_batch_workspace_bytes": (c_int64, [POINTER(ScarletBatch)]),
     "scarlet_fit": (c_int, [POINTER(ScarletBatch), c_int, c_double, c_int, c_int, _P]),

@@ -83,7 +83,19 @@ def _as_numpy_mask(mask):
 
 def trim(X, min_value=0):
     """Tight box around the pixels of the 2-D array X that exceed `min_value`
-    (reference bbox.py:174-193)."""
+    (reference bbox.py:174-193).  Device tensors are reduced by the HIP library."""
+    if hasattr(X, "is_cuda") and X.is_cuda:
+        import torch
+        from . import _lib
+        t = X if (X.dtype == torch.float32 and X.is_contiguous()) else X.to(torch.float32).contiguous()
+        box = torch.zeros(4, dtype=torch.int32, device=t.device)
+        _lib.check(_lib.lib.scarlet_trim(_lib.ptr(t), 1, t.shape[0], t.shape[1], float(min_value), _lib.ptr(box),
+                                         _lib.stream_ptr()))
+        b = box.cpu().numpy()
+        if b[1] < 0:
+            # the reference takes min() of an empty index list here
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")
+        return Box.from_bounds(int(b[0]), int(b[1]), int(b[2]), int(b[3]))
     ys, xs = np.nonzero(_as_numpy_mask(X > min_value))
     return Box.from_bounds(int(ys.min()), int(ys.max()), int(xs.min()), int(xs.max()))
 

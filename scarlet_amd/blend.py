@@ -184,8 +184,6 @@ class Blend(ComponentTree):
         b._ensure_mse_capacity(max_iter)
         b.active.fill_(1)
         multi = self._obs_batches is not None
-        if multi and approximate_L:
-            raise NotImplementedError("approximate_L with several observations")
         for _ in range(max_iter):
             cur = int(b.cur[0].item())
             # Prior hooks (reference blend.py:86-90, component.py:177-187) run on the factors
@@ -223,6 +221,12 @@ class Blend(ComponentTree):
                         g_sed[:, sl] += ob.sed[1][0]; g_morph += ob.morph[1][0]
                         loss += float(ob.mse_buf[0, 0].item())
                     b.mse_buf[0, it_idx] = loss
+                    if approximate_L:
+                        # blend.py:189-201 on the summed loss: crude bound, doubled when the loss rose
+                        L = np.array([float((x_morph.double() ** 2).sum().item()),
+                                      float((x_sed.double() ** 2).sum().item())])
+                        if it_idx >= 1 and loss > float(b.mse_buf[0, it_idx - 1].item()):
+                            L *= 2
                 else:
                     g_sed, g_morph = b.sed[1 - cur][0].clone(), b.morph[1 - cur][0].clone()
                 n_obs = len(self.observations)

@@ -18,6 +18,7 @@
 #include "fused2.h"
 #include "bigk.h"
 #include "psf_path.h"
+#include "extras.h"
 
 __constant__ unsigned short sc_nfl_table[SC_NFL_MAX];
 
@@ -344,6 +345,57 @@ extern "C" int scarlet_normalize(float *sed, float *morph, int n, int B, int HW,
     if (!sed || !morph || n < 0 || B <= 0 || HW <= 0) return set_err(SCARLET_E_ARG, "bad normalize arguments");
     if (n == 0) return SCARLET_OK;
     hipLaunchKernelGGL(k_normalize, dim3(n), dim3(SC_BLOCK), 0, (hipStream_t)stream, sed, morph, B, HW, type);
+    HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
+}
+
+// ---- measurement.threshold / update.threshold / bbox.trim / update.translation (extras.h)
+extern "C" int scarlet_log_range(const float *x, int n, int64_t count, double *out, void *stream)
+{
+    if (n < 0 || count <= 0 || !x || !out) return set_err(SCARLET_E_ARG, "bad log_range arguments");
+    if (n == 0) return SCARLET_OK;
+    hipLaunchKernelGGL(k_log_range, dim3(n), dim3(SC_BLOCK), 0, (hipStream_t)stream, x, count, out);
+    HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
+}
+extern "C" int scarlet_log_hist(const float *x, int n, int64_t count, const double *edges,
+                                const int32_t *nbins, int32_t *hist, void *stream)
+{
+    if (n < 0 || count <= 0 || !x || !edges || !nbins || !hist) return set_err(SCARLET_E_ARG, "bad log_hist arguments");
+    if (n == 0) return SCARLET_OK;
+    hipLaunchKernelGGL(k_log_hist, dim3(n), dim3(SC_BLOCK), 0, (hipStream_t)stream, x, count, edges, nbins, hist);
+    HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
+}
+extern "C" int scarlet_cut_below(float *x, int64_t count, double thresh, void *stream)
+{
+    if (count < 0 || (count > 0 && !x)) return set_err(SCARLET_E_ARG, "bad cut_below arguments");
+    if (count == 0) return SCARLET_OK;
+    int64_t blocks = (count + SC_BLOCK - 1) / SC_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_cut_below, dim3((unsigned)blocks), dim3(SC_BLOCK), 0, (hipStream_t)stream, x, count, thresh);
+    HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
+}
+extern "C" int scarlet_trim(const float *x, int n, int H, int W, float min_value, int32_t *box, void *stream)
+{
+    if (n < 0 || H <= 0 || W <= 0 || !x || !box) return set_err(SCARLET_E_ARG, "bad trim arguments");
+    if (n == 0) return SCARLET_OK;
+    hipLaunchKernelGGL(k_trim, dim3(n), dim3(SC_BLOCK), 0, (hipStream_t)stream, x, H, W, min_value, box);
+    HIP_TRY(hipGetLastError());
+    return SCARLET_OK;
+}
+extern "C" int scarlet_resample(const float *in, float *out, int n, int H, int W, const double *taps,
+                                const int32_t *win0, int ny, int nx, void *stream)
+{
+    if (n < 0 || H <= 0 || W <= 0 || !in || !out || in == out || !taps || !win0)
+        return set_err(SCARLET_E_ARG, "bad resample arguments");
+    if (ny < 1 || nx < 1 || ny > SC_TAPS_MAX || nx > SC_TAPS_MAX)
+        return set_err(SCARLET_E_ARG, "resampling kernels have 1 to 8 taps");
+    if (n == 0) return SCARLET_OK;
+    int bx = (H * W + SC_BLOCK - 1) / SC_BLOCK;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(k_resample, dim3(bx, n), dim3(SC_BLOCK), 0, (hipStream_t)stream, in, out, H, W, taps, win0, ny, nx);
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;
 }

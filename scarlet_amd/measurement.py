@@ -54,6 +54,32 @@ def psf_weighted_centroid(morph, psf, pixel_center):
 
 
 def threshold(morph):
-    """Log-histogram cut of the reference (measurement.py:97-112): disabled in the reference's
-    own pipeline (source.py:416-418) and outside the hot path."""
-    raise NotImplementedError("measurement.threshold is outside the accelerated path")
+    """Noise cut from the histogram of log10(positive pixels) (reference measurement.py:97-112):
+    50 equal bins, size/10 when fewer than 500 pixels are positive (a single bin means no cut);
+    the cut is the lower edge of the last empty bin, 0 when no bin is empty.  Returns
+    (thresh, bins).  Range and histogram are device kernels; the 51 edges are tabulated with
+    np.linspace exactly as np.histogram does."""
+    torch = _lib.require_gpu()
+    with _OnDevice(morph) as t:
+        rng = torch.zeros((1, 3), dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib.scarlet_log_range(_lib.ptr(t), 1, t.numel(), _lib.ptr(rng), _lib.stream_ptr()))
+        size, lo, hi = rng.cpu().numpy()[0]
+        bins = 50
+        if size < 500:
+            bins = max(int(size / 10), 1)
+            if bins == 1:
+                return 0, bins
+        if lo == hi:                      # np.histogram widens a degenerate range by +-0.5
+            lo, hi = lo - 0.5, hi + 0.5
+        edges = np.zeros((1, 51), dtype=np.float64)
+        edges[0, :bins + 1] = np.linspace(lo, hi, bins + 1, endpoint=True, dtype=np.float64)
+        e = torch.as_tensor(edges).cuda()
+        nb = torch.as_tensor(np.array([bins], dtype=np.int32)).cuda()
+        hist = torch.zeros((1, 50), dtype=torch.int32, device="cuda")
+        _lib.check(_lib.lib.scarlet_log_hist(_lib.ptr(t), 1, t.numel(), _lib.ptr(e), _lib.ptr(nb),
+                                             _lib.ptr(hist), _lib.stream_ptr()))
+        h = hist.cpu().numpy()[0, :bins]
+    cutoff = np.where(h == 0)[0]
+    if len(cutoff) == 0:
+        return 0, bins
+    return 10 ** edges[0, cutoff[-1]], bins

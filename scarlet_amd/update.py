@@ -8,6 +8,8 @@ import numpy as np
 from . import _lib
 from . import operator
 from . import measurement
+from . import interpolation
+from .bbox import trim
 
 
 def _elementwise(fn, t, *args):
@@ -60,9 +62,16 @@ def sparse_l1(component, thresh):
 
 
 def threshold(component):
-    """Noise cut from the log histogram (reference update.py:85-103): disabled in the
-    reference's own pipeline (source.py:416-418), outside the accelerated path."""
-    raise NotImplementedError("update.threshold is outside the accelerated path")
+    """Zero the pixels below the log-histogram noise cut and record the tight box of what is
+    left in component.bboxes["thresh"] (reference update.py:85-103)."""
+    thresh, _bins = measurement.threshold(component.morph)
+    m = component.morph
+    _lib.check(_lib.lib.scarlet_cut_below(_lib.ptr(m), m.numel(), ctypes.c_double(float(thresh)), _lib.stream_ptr()))
+    bbox = trim(m)
+    if not hasattr(component, "bboxes"):
+        component.bboxes = {}
+    component.bboxes["thresh"] = bbox
+    return component
 
 
 def _bbox_window(component, pixel_center, bbox):
@@ -92,10 +101,14 @@ def monotonic(component, pixel_center, use_nearest=False, thresh=0, exact=False,
     return component
 
 
-def translation(component, direction=1, kernel=None, padding=3):
-    """Sub-pixel translation by Lanczos resampling (reference update.py:159-167): never called
-    by the reference's pipelines, outside the accelerated path."""
-    raise NotImplementedError("update.translation is outside the accelerated path")
+def translation(component, direction=1, kernel=interpolation.lanczos, padding=3):
+    """Shift the morphology by direction * component.shift with a separable resampling kernel
+    (reference update.py:159-167; Lanczos-3 by default)."""
+    dy, dx = component.shift
+    dy *= direction
+    dx *= direction
+    component.morph[:] = interpolation.fft_resample(component.morph, dy, dx, kernel=kernel)
+    return component
 
 
 def symmetric(component, pixel_center, algorithm="kspace", bbox=None, fill=None, strength=.5):

@@ -396,3 +396,96 @@ def test_several_observations_match_the_reference(scarlet):
         assert rel_err(np.array([npy(c.morph) for c in blend.components]), g[tag + "_morph"]) < 2e-5
         assert rel_err(np.array([npy(c.sed) for c in blend.components]), g[tag + "_sed"]) < 2e-5
         assert_array_equal(np.array([c.pixel_center for c in blend.components]), g[tag + "_center"])
+
+
+def test_approximate_L_with_two_observations(scarlet):
+    """fit(approximate_L=True) on a blend with two observations (reference blend.py:189-201,
+    219-220), against a fixture generated by the reference (gen_fit_extras2)."""
+    from scarlet_amd import synth
+    g = load_golden("fit_extras2")
+    scn = synth.make_scene(7)
+    images = scn["images"]
+    ch = list("grizy")
+    frame = scarlet.Frame(images.shape, channels=ch)
+    full = scarlet.Observation(images, channels=ch).match(frame)
+    srcs = [scarlet.ExtendedSource(frame, tuple(int(v) for v in p), full, np.ones(5) * 0.1)
+            for p in scn["centers"]]
+    obs = [scarlet.Observation(images, channels=ch).match(frame),
+           scarlet.Observation(g["images2"], channels=ch).match(frame)]
+    blend = scarlet.Blend(srcs, obs)
+    blend.fit(12, e_rel=0, approximate_L=True)
+    assert blend.it == 12
+    assert rel_err(blend.mse, g["mse"]) < 1e-5
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["morph"]) < 2e-5
+    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["sed"]) < 2e-5
+    assert_array_equal(np.array([c.pixel_center for c in blend.components]), g["center"])
+
+
+def test_threshold_matches_the_reference(scarlet):
+    """measurement.threshold / update.threshold (reference measurement.py:97-112, update.py:85-103;
+    the reference's tests/test_update.py:98-117 is case 0) on reference-generated fixtures: cut value
+    to 1e-6 relative (float64 log10 on the device vs numpy's in the array's dtype), number of bins,
+    surviving pixels and the trimmed box exactly."""
+    g = load_golden("thresh_translate")
+    for i in range(int(g["thr_n"])):
+        for tag in ("f64", "f32"):
+            m = g["thr_in%d_%s" % (i, tag)]
+            want_t, want_b = g["thr_value%d_%s" % (i, tag)]
+            frame = scarlet.Frame((3,) + m.shape)
+            c = scarlet.Component(frame, np.arange(3.), m.copy())
+            t, b = scarlet.measurement.threshold(c.morph)
+            assert b == int(want_b)
+            assert abs(float(t) - want_t) <= 1e-6 * abs(want_t)
+            scarlet.update.threshold(c)
+            assert_array_equal(npy(c.sed), np.arange(3.))
+            assert_array_equal(npy(c.morph), g["thr_out%d_%s" % (i, tag)].astype(np.float32))
+            bb = c.bboxes["thresh"]
+            assert (bb.bottom, bb.top, bb.left, bb.right) == tuple(g["thr_box%d_%s" % (i, tag)])
+    # the reference's assertion itself
+    m = g["thr_in0_f64"]
+    frame = scarlet.Frame((5,) + m.shape)
+    src = scarlet.Component(frame, np.arange(5.), m.copy())
+    scarlet.update.threshold(src)
+    truth = np.zeros(m.shape)
+    truth[7:14, 7:14] = m[7:14, 7:14]
+    assert_almost_equal(npy(src.morph), truth, decimal=6)
+    assert src.bboxes["thresh"] == scarlet.bbox.Box((7, 7), 7, 7)
+    # batched device entry points: every plane of a stack gets its own range / histogram / box
+    import ctypes
+    L = scarlet._lib
+    stack = torch.as_tensor(np.stack([g["thr_in1_f32"], g["thr_in2_f32"]]).astype(np.float32)).cuda()
+    rng = torch.zeros((2, 3), dtype=torch.float64, device="cuda")
+    L.check(L.lib.scarlet_log_range(L.ptr(stack), 2, 64 * 64, L.ptr(rng), L.stream_ptr()))
+    box = torch.zeros((2, 4), dtype=torch.int32, device="cuda")
+    L.check(L.lib.scarlet_trim(L.ptr(stack), 2, 64, 64, ctypes.c_float(0.), L.ptr(box), L.stream_ptr()))
+    for k in range(2):
+        pos = stack[k][stack[k] > 0].cpu().numpy().astype(np.float64)
+        assert rng[k, 0].item() == pos.size
+        assert_almost_equal(rng[k, 1:].cpu().numpy(), [np.log10(pos).min(), np.log10(pos).max()], decimal=12)
+        ys, xs = np.nonzero(stack[k].cpu().numpy() > 0)
+        assert_array_equal(box[k].cpu().numpy(), [ys.min(), ys.max(), xs.min(), xs.max()])
+    with pytest.raises(ValueError):
+        scarlet.bbox.trim(torch.zeros((8, 8), device="cuda"))
+
+
+def test_translation_matches_the_reference(scarlet):
+    """update.translation / interpolation.fft_resample (reference update.py:159-167,
+    interpolation.py:408-448): reference-generated Lanczos shifts (float64 fixtures, float32 device
+    planes: 1e-5 max-norm relative, the north_star tolerance) and the bilinear known answer of the
+    reference's tests/test_interpolation.py:365-393."""
+    g = load_golden("thresh_translate")
+    img = g["tr_in"]
+    for k, sh in enumerate(g["tr_shifts"]):
+        for d in (1, -1):
+            frame = scarlet.Frame((3,) + img.shape)
+            c = scarlet.Component(frame, np.arange(3.), img.copy())
+            c.shift = (float(sh[0]), float(sh[1]))
+            scarlet.update.translation(c, direction=d)
+            assert rel_err(npy(c.morph), g["tr_out%d_%d" % (k, d)]) < 1e-5
+    im = g["bil_in"]
+    for dy, dx, key in ((.217, -.026, "bil_out0"), (-.691, .321, "bil_out1")):
+        res = scarlet.interpolation.fft_resample(im, dy, dx, kernel=scarlet.interpolation.bilinear)
+        assert res.shape == im.shape
+        assert rel_err(res, g[key]) < 1e-6
+    with pytest.raises(ValueError):
+        scarlet.interpolation.lanczos(1.5)

@@ -452,3 +452,64 @@ def test_fit_extras_fixture_several_observations():
         assert rel_err(np.array([c.morph for c in sc.sources]), g[tag + "_morph"]) < 2e-5
         assert rel_err(np.array([c.sed for c in sc.sources]), g[tag + "_sed"]) < 2e-5
         assert_array_equal(np.array([c.center for c in sc.sources]), g[tag + "_center"])
+
+
+def test_fit_extras2_fixture_approximate_L_with_two_observations():
+    """approximate_L with two observations (blend.py:189-201, 219-220); reference-generated."""
+    g = load_golden("fit_extras2")
+    scn = synth.make_scene(7)
+    images = scn["images"]
+    sc = pgm.make_extended_scene(images, scn["centers"], np.ones(5) * 0.1)
+    sc.observations = [dict(images=images), dict(images=g["images2"])]
+    pgm.fit(sc, 12, e_rel=0, approximate_L=True)
+    assert rel_err(sc.mse, g["mse"]) < 1e-5
+    assert rel_err(np.array([c.morph for c in sc.sources]), g["morph"]) < 2e-5
+    assert rel_err(np.array([c.sed for c in sc.sources]), g["sed"]) < 2e-5
+    assert_array_equal(np.array([c.center for c in sc.sources]), g["center"])
+
+
+def test_threshold_fixture_and_reference_case():
+    """measurement.threshold / update.threshold (measurement.py:97-112, update.py:85-103) against
+    reference-generated fixtures; case 0 is the reference's own test (tests/test_update.py:98-117:
+    the 7x7 signal box survives, bbox (7,7)+7x7)."""
+    g = load_golden("thresh_translate")
+    for i in range(int(g["thr_n"])):
+        for tag in ("f64", "f32"):
+            m = g["thr_in%d_%s" % (i, tag)].copy()
+            t, b = pgm.threshold(m)
+            assert (float(t), float(b)) == tuple(g["thr_value%d_%s" % (i, tag)])
+            _, box = pgm.update_threshold(m)
+            assert_array_equal(m, g["thr_out%d_%s" % (i, tag)])
+            assert tuple(box) == tuple(g["thr_box%d_%s" % (i, tag)])
+    m = g["thr_in0_f64"].copy()
+    truth = np.zeros(m.shape)
+    truth[7:14, 7:14] = m[7:14, 7:14]
+    _, box = pgm.update_threshold(m)
+    assert_almost_equal(m, truth)
+    assert box == (7, 13, 7, 13)
+
+
+def test_translation_fixture_and_reference_bilinear_case():
+    """interpolation.fft_resample / update.translation (interpolation.py:408-448, update.py:159-167):
+    reference-generated Lanczos shifts, and the bilinear known answer of
+    tests/test_interpolation.py:365-393 (a shifted image is the four-neighbour blend)."""
+    g = load_golden("thresh_translate")
+    img = g["tr_in"]
+    for k, sh in enumerate(g["tr_shifts"]):
+        for d in (1, -1):
+            out = pgm.update_translation(img.copy(), sh, d)
+            assert_almost_equal(out, g["tr_out%d_%d" % (k, d)], decimal=13)
+    _img = np.arange(36).reshape(6, 6)
+    im = np.zeros((11, 11))
+    im[2:8, 2:8] = _img
+    for dy, dx, key in ((.217, -.026, "bil_out0"), (-.691, .321, "bil_out1")):
+        res = pgm.fft_resample(im, dy, dx, pgm.bilinear)
+        assert_almost_equal(res, g[key], decimal=13)
+        Dy, Dx = abs(dy), abs(dx)
+        sy, sx = (1 if dy > 0 else -1), (1 if dx > 0 else -1)
+        truth = np.zeros(im.shape)
+        truth[2:8, 2:8] += _img * (1 - Dx) * (1 - Dy)
+        truth[2:8, 2 + sx:8 + sx] += _img * Dx * (1 - Dy)
+        truth[2 + sy:8 + sy, 2:8] += _img * (1 - Dx) * Dy
+        truth[2 + sy:8 + sy, 2 + sx:8 + sx] += _img * Dx * Dy
+        assert_almost_equal(res, truth)
