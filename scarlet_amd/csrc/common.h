@@ -83,6 +83,43 @@ __device__ __forceinline__ void wave_sum_lastrow(float (&v)[N]) {
         v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), SC_DPP_BCAST31, 0xc, 0xf, false));
 }
 
+// Sums of N independent float values over the 16-lane ROWS of the wave with a third of the DPP adds
+// of wave_sum_lastrow: the first two butterfly steps (lane ^ 1, lane ^ 2) also halve the number of
+// live values -- after a step each lane keeps only the values whose index bit equals its lane bit
+// -- and the two remaining in-row steps (rotations by 4 and 8 lanes, which keep lane & 3) run on
+// ceil(N / 4) registers.  Afterwards EVERY lane of row R holds, in out[m], the sum over row R of
+// value 4 m + (lane & 3); the caller adds the four rows (they go to LDS as four partials).
+// (3 N / 2 + 3 N / 4 + N / 2 instructions instead of 6 N.)
+#define SC_DPP_ROR4 0x124
+#define SC_DPP_ROR8 0x128
+template <int N>
+__device__ __forceinline__ void wave_rowsum_quads(const float (&v)[N], float (&out)[(N + 3) / 4]) {
+    constexpr int N2 = (N + 1) / 2, N4 = (N + 3) / 4;
+    const int lane = threadIdx.x & (SC_WAVE - 1);
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float r[N2];
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+        const float a = v[2 * i] + dpp_mov<SC_DPP_XOR1>(v[2 * i]);
+        if (2 * i + 1 < N) {
+            const float b = v[2 * i + 1] + dpp_mov<SC_DPP_XOR1>(v[2 * i + 1]);
+            r[i] = b0 ? b : a;
+        } else r[i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+        const float a = r[2 * i] + dpp_mov<SC_DPP_XOR2>(r[2 * i]);
+        if (2 * i + 1 < N2) {
+            const float b = r[2 * i + 1] + dpp_mov<SC_DPP_XOR2>(r[2 * i + 1]);
+            out[i] = b1 ? b : a;
+        } else out[i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < N4; ++i) out[i] += dpp_mov<SC_DPP_ROR4>(out[i]);
+#pragma unroll
+    for (int i = 0; i < N4; ++i) out[i] += dpp_mov<SC_DPP_ROR8>(out[i]);
+}
+
 // Block-wide sum of a double; `red` is SC_NWAVES doubles of LDS.  All threads get the result.
 __device__ __forceinline__ double block_sum(double v, double *red) {
     v = wave_sum(v);

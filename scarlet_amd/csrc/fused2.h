@@ -26,16 +26,40 @@
 #define SC_PAIR_VEC_FLOATS 512       // av, bv, cv (128 each) + one zv (64) per wave of the pair
 
 // FFT lengths of a window of half-size r (h = 2 r + 1): fl[0][r] = next_fast_len(2 h + 10) and
-// fl[1][r] = the first EVEN fast length from there (fft.py:95-115 via operator.py:253-288),
-// tabulated in LDS at kernel start so that the constraint phase does not wait on constant loads
-__device__ __forceinline__ void ks_fill_lengths(unsigned short (*fl)[32], int tid)
-{
-    if (tid < 32) {
-        const int F = dev_next_fast_len(2 * (2 * tid + 1) + 10);
-        int Fe = F;
-        while (Fe & 1) Fe = dev_next_fast_len(Fe + 1);
-        fl[0][tid] = (unsigned short)F; fl[1][tid] = (unsigned short)Fe;
+// fl[1][r] = the first EVEN fast length from there (fft.py:95-115 via operator.py:253-288).  The
+// 64 entries are compile-time constants (r < 32: windows of up to 63 pixels); every workgroup copies
+// them into LDS at kernel start -- requested before the tile loads, written after they are issued --
+// so that the constraint phase does not wait on constant loads.
+struct KsLengths {
+    unsigned short v[2][32];
+    static constexpr int fast_len(int n)
+    {   // smallest 2^a 3^b 5^c >= n (scipy.fftpack.next_fast_len)
+        for (int m = n;; ++m) {
+            int q = m;
+            while (q % 2 == 0) q /= 2;
+            while (q % 3 == 0) q /= 3;
+            while (q % 5 == 0) q /= 5;
+            if (q == 1) return m;
+        }
     }
+    constexpr KsLengths() : v{}
+    {
+        for (int r = 0; r < 32; ++r) {
+            const int F = fast_len(2 * (2 * r + 1) + 10);
+            int Fe = F;
+            while (Fe & 1) Fe = fast_len(Fe + 1);
+            v[0][r] = (unsigned short)F; v[1][r] = (unsigned short)Fe;
+        }
+    }
+};
+__device__ const KsLengths sc_ks_lengths = KsLengths();
+__device__ __forceinline__ unsigned ks_request_lengths(int tid)
+{
+    return tid < 64 ? (unsigned)(&sc_ks_lengths.v[0][0])[tid] : 0u;
+}
+__device__ __forceinline__ void ks_fill_lengths(unsigned short (*fl)[32], int tid, unsigned requested)
+{
+    if (tid < 64) (&fl[0][0])[tid] = (unsigned short)requested;
 }
 __device__ __forceinline__ KsGeom ks_geom(const SymWindow &s, const unsigned short (*fl)[32])
 {
@@ -47,22 +71,28 @@ __device__ __forceinline__ KsGeom ks_geom(const SymWindow &s, const unsigned sho
     return g;
 }
 
-template <int KM, int BM>
+// XS > 0: the exact-shape instance -- K == KM, B == BM, H == W == XS, scalar weight 1 and the default
+// constraint pipeline (symmetric, monotonic, no sparsity) are compile-time facts, so the index
+// arithmetic, the bounds predicates and the pipeline switches fold away (same arithmetic on the
+// pixels, bit-identical results).  XS == 0: everything is read from the arguments.
+template <int KM, int BM, int XS = 0>
 __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
 {
     static_assert(KM <= 4, "one pair of waves per component");
+    constexpr bool X = XS > 0;
     extern __shared__ __align__(16) float lds[];
     const int s = blockIdx.x;
     if (!a.active[s]) return;
-    const int K = a.K, B = a.B, H = a.H, W = a.W, HW = H * W, LW = tile_stride(W);
+    const int K = X ? KM : a.K, B = X ? BM : a.B, H = X ? XS : a.H, W = X ? XS : a.W, HW = H * W, LW = tile_stride(W);
     const int tile_floats = H * LW;
+    const bool symmetric = X ? true : a.symmetric != 0, monotonic = X ? true : a.monotonic != 0;
     float *tiles = lds;
     float *vecs = lds + (size_t)K * tile_floats;
     constexpr int NG = KM * (KM + 1) / 2;
     constexpr int NP = 1 + KM * BM;
     constexpr int GPT = 2;                       // float4 groups per thread in phases 0/1 (H, W <= 64)
     constexpr int GPW = 8;                       // float4 groups per lane in the pair's final pass
-    __shared__ float red[SC_NW2][NP > NG ? NP : NG];      // per-wave partial sums
+    __shared__ float red[4 * SC_NW2][NP > NG ? NP : NG];  // partial sums per 16-lane row of every wave
     __shared__ double tot[NP > NG ? NP : NG];
     __shared__ double mat[2][KM * KM > BM * BM ? KM * KM : BM * BM];
     __shared__ float sed_s[KM * BM], sed_new[KM * BM];
@@ -81,9 +111,10 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     const int it_new = a.it[s] + 1;
     const int ngroups = HW >> 2, gpr = W >> 2;           // float4 groups, groups per row
     const float *img = a.images + (size_t)s * B * HW;
-    const float *wgt = a.weights ? a.weights + (size_t)s * B * HW : nullptr;
+    const float *wgt = (!X && a.weights) ? a.weights + (size_t)s * B * HW : nullptr;
 #define STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)s * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
+    const unsigned fl_req = ks_request_lengths(tid);
 
     // ---------------- phase 0: issue every global load, tiles -> LDS, Gram
     float4 mreg[GPT][KM];
@@ -107,14 +138,16 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     };
     load_images(0);
     for (int i = tid; i < K * B; i += SC_FB2) sed_s[(i / B) * BM + (i % B)] = sed_in[i];
-    ks_fill_lengths(fl_s, tid);
+    ks_fill_lengths(fl_s, tid, fl_req);
     if (tid < 2 * KM) (&pair_flag[0][0])[tid] = 0;
     const bool small_side = (K <= B);          // nonzero spectrum of A^T A == that of A A^T
     __syncthreads();                           // sed_s visible
     {
-        float gram[NG];
+        // packed-f32 products (v_pk_fma_f32): the .x lanes of gram2 sum pixels 0 and 2 of the groups,
+        // the .y lanes pixels 1 and 3
+        f32x2 gram2[NG];
 #pragma unroll
-        for (int i = 0; i < NG; ++i) gram[i] = 0.f;
+        for (int i = 0; i < NG; ++i) gram2[i] = (f32x2){0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < GPT; ++j) {
             const int g = tid + j * SC_FB2;
@@ -129,21 +162,23 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
 #pragma unroll
                     for (int k2 = k; k2 < KM; ++k2) {
                         const float4 p = mreg[j][k], q = mreg[j][k2];
-                        gram[gi] += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
+                        gram2[gi] += (f32x2){p.x, p.y} * (f32x2){q.x, q.y};
+                        gram2[gi] += (f32x2){p.z, p.w} * (f32x2){q.z, q.w};
                         ++gi;
                     }
             }
         }
-        wave_sum_lastrow(gram);                 // float partials per wave, float64 across the waves
-        if (lane == SC_WAVE - 1) {
-            int gi = 0, go = 0;
+        float gram[NG];
 #pragma unroll
-            for (int k = 0; k < KM; ++k)
+        for (int i = 0; i < NG; ++i) gram[i] = gram2[i].x + gram2[i].y;
+        // float partials per 16-lane row (float64 across the 4 x 8 rows): red[4 wid + row][gi], gi =
+        // packed upper-triangle index over KM x KM; lane & 3 = q holds the row sums of the entries 4 m + q
+        float gq[(NG + 3) / 4];
+        wave_rowsum_quads(gram, gq);
+        if ((lane & 12) == 12) {
 #pragma unroll
-                for (int k2 = k; k2 < KM; ++k2) {
-                    if (k < K && k2 < K) red[wid][go++] = gram[gi];
-                    ++gi;
-                }
+            for (int m = 0; m < (NG + 3) / 4; ++m)
+                if (4 * m + 3 < NG || 4 * m + (lane & 3) < NG) red[4 * wid + (lane >> 4)][4 * m + (lane & 3)] = gq[m];
         }
     }
 #pragma unroll
@@ -156,10 +191,10 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         if (lane < K * K) {
             const int k = lane / K, k2 = lane - k * K;
             const int lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
-            const int go = lo * K - (lo * (lo - 1)) / 2 + (hi - lo);     // packed upper-triangle index
+            const int go = lo * KM - (lo * (lo - 1)) / 2 + (hi - lo);    // packed upper-triangle index (KM x KM)
             double r = 0;
 #pragma unroll
-            for (int w = 0; w < SC_NW2; ++w) r += (double)red[w][go];
+            for (int w = 0; w < 4 * SC_NW2; ++w) r += (double)red[w][go];
             mat[0][k * KM + k2] = r;
         }
         if (lane < (small_side ? K * K : B * B)) {
@@ -206,7 +241,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
 #pragma unroll
             for (int b = 0; b < BM; ++b) dsed2[k][b] = (f32x2){0.f, 0.f};
         f32x2 loss2 = {0.f, 0.f};
-        const f32x2 ws2 = {a.weight_scalar, a.weight_scalar};
+        const f32x2 ws2 = {a.weight_scalar, a.weight_scalar};      // (exact instance: 1, the multiplications fold away)
 #pragma unroll
         for (int j = 0; j < GPT; ++j) {
             const int g = tid + j * SC_FB2;
@@ -234,9 +269,9 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
                             f32x2 model = sed[0][b] * m2[0][p];
 #pragma unroll
                             for (int k = 1; k < KM; ++k) model += sed[k][b] * m2[k][p];
-                            const f32x2 d = ww2[p] * (model - im2[p]);
+                            const f32x2 d = X ? model - im2[p] : ww2[p] * (model - im2[p]);
                             loss2 += d * d;
-                            const f32x2 gg = ww2[p] * d;
+                            const f32x2 gg = X ? d : ww2[p] * d;
 #pragma unroll
                             for (int k = 0; k < KM; ++k) { dsed2[k][b] += gg * m2[k][p]; gm2[k][p] += sed[k][b] * gg; }
                         }
@@ -256,22 +291,23 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         for (int k = 0; k < KM; ++k)
 #pragma unroll
             for (int b = 0; b < BM; ++b) part[1 + k * BM + b] = dsed2[k][b].x + dsed2[k][b].y;
-        wave_sum_lastrow(part);                 // float partials per wave, float64 across the waves
-        if (lane == SC_WAVE - 1) {
-            red[wid][0] = part[0];
+        // float partials per 16-lane row (float64 across the 4 x 8 rows): red[4 wid + row][i], i = 0
+        // (loss) or 1 + k * BM + b; lane & 3 = q holds the row sums of the entries 4 m + q
+        float pq[(NP + 3) / 4];
+        wave_rowsum_quads(part, pq);
+        if ((lane & 12) == 12) {
 #pragma unroll
-            for (int k = 0; k < KM; ++k)
-#pragma unroll
-                for (int b = 0; b < BM; ++b)
-                    if (k < K && b < B) red[wid][1 + k * B + b] = part[1 + k * BM + b];
+            for (int m = 0; m < (NP + 3) / 4; ++m)
+                if (4 * m + 3 < NP || 4 * m + (lane & 3) < NP) red[4 * wid + (lane >> 4)][4 * m + (lane & 3)] = pq[m];
         }
     }
     __syncthreads();
     STAMP(3);
     for (int i = tid; i < 1 + K * B; i += SC_FB2) {
+        const int src = i == 0 ? 0 : 1 + ((i - 1) / B) * BM + (i - 1) % B;     // (k, b) of the K x B list in the KM x BM layout
         double r = 0;
 #pragma unroll
-        for (int w = 0; w < SC_NW2; ++w) r += (double)red[w][i];
+        for (int w = 0; w < 4 * SC_NW2; ++w) r += (double)red[w][src];
         tot[i] = r;
     }
     __syncthreads();
@@ -317,7 +353,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         cy = a.centers[2 * c]; cx = a.centers[2 * c + 1];
         wave_max_pixel(t, cy, cx, stat);            // both waves of the pair, identically
         cy = uniform(cy); cx = uniform(cx);
-        if (a.symmetric) {
+        if (symmetric) {
             double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
             if (it_new % 5 == 0) {
                 // (the partner recomputes the same values: whatever it read from a.shifts is overwritten)
@@ -369,7 +405,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     if (mine && !lead) load_last();                 // the idle wave of the pair: before the barrier
     if (mine && lead) {
         int lstop = 1 << 30;                        // last sweep level computed (early exit)
-        if (a.monotonic) wave_monotonic<float>(t, cy, cx, 0.f, &lstop);
+        if (monotonic) wave_monotonic<float>(t, cy, cx, 0.f, &lstop);
         if (lane == 0) { lstop_s[k] = lstop; a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
         load_last();
     }
@@ -378,8 +414,8 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     // ---- sparsity, positivity (update.py:71-82, 27-32), normalisation (update.py:62-65),
     // store, convergence sums: one pass over the LDS tile, float4 groups split between the pair
     float norm = 0.f;
-    float l0 = a.l0_thresh >= 0.f ? a.l0_thresh * step_morph : -1.f;
-    float l1 = a.l1_thresh >= 0.f ? a.l1_thresh * step_morph : -1.f;
+    float l0 = (!X && a.l0_thresh >= 0.f) ? a.l0_thresh * step_morph : -1.f;
+    float l1 = (!X && a.l1_thresh >= 0.f) ? a.l1_thresh * step_morph : -1.f;
     auto sparse = [&](float v) {
         if (l0 >= 0.f && fabsf(v) < l0) v = 0.f;
         if (l1 >= 0.f) {
@@ -388,7 +424,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         }
         return v;
     };
-    if (!a.monotonic) {
+    if (!monotonic) {
         float vmax = -INFINITY;
         bool anynan = false;
         if (mine) {

@@ -1082,7 +1082,18 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
         hipLaunchKernelGGL((k_iterate2<4, BM_>), dim3(b->S), dim3(SC_FB2), lds2, st, f);               \
         prof_stop(st);                                                                                 \
     } while (0)
-        LAUNCH_ITERATE2(5);
+        // the headline shape (BASELINE configs[1]/[3]: 4 sources, 5 bands, 64 x 64, default pipeline) has
+        // an instance with every shape and switch folded at compile time
+        const bool exact64 = b->K == 4 && b->B == 5 && b->H == 64 && b->W == 64 && !b->weights && b->weight_scalar == 1.0f && b->symmetric &&
+                             b->monotonic && b->l0_thresh < 0.f && b->l1_thresh < 0.f && !getenv("SCARLET_NO_EXACT");
+        if (exact64) {
+            rc = allow_lds(k_iterate2<4, 5, 64>, lds2);
+            if (rc) return rc;
+            prof_start(4, st);
+            hipLaunchKernelGGL((k_iterate2<4, 5, 64>), dim3(b->S), dim3(SC_FB2), lds2, st, f);
+            prof_stop(st);
+        } else
+            LAUNCH_ITERATE2(5);
 #undef LAUNCH_ITERATE2
         HIP_TRY(hipGetLastError());
         return SCARLET_OK;

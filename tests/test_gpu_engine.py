@@ -137,6 +137,36 @@ def test_batch_independence_and_determinism(BB):
         np.testing.assert_array_equal(a[perm], c)
 
 
+def test_exact_shape_instance_is_bit_identical_to_the_generic_kernel(BB, monkeypatch):
+    """k_iterate2<4,5,64> (K, B, H, W and the default pipeline folded at compile time; chosen by
+    launch_fused for BASELINE's headline shape) performs the same arithmetic as k_iterate2<4,5,0>:
+    factors, losses, centres, shifts and flags must agree bit for bit, also across an iteration
+    with the centroid update (it % 5 == 0) and with fixed factors."""
+    from scarlet_amd import synth
+    S = 48
+    data = synth.make_batch(1200, S)
+    fix = np.zeros((S, 4), dtype=np.uint8)
+    fix[::3, 1] = 1
+    def run(generic, **kw):
+        if generic:
+            monkeypatch.setenv("SCARLET_NO_EXACT", "1")
+        else:
+            monkeypatch.delenv("SCARLET_NO_EXACT", raising=False)
+        b = BB(data["images"], data["centers"])
+        for name, arr in kw.items():
+            setattr(b, name, torch.as_tensor(arr).cuda())
+        b._fill_struct()
+        b.init_extended(np.ones(5) * 0.1)
+        b.fit(11, e_rel=1e-3)
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (b.morph_current, b.sed_current, b.mse_buf[:, :11], b.centers, b.shifts,
+                                          b.flags, b.it, b.lipschitz)]
+    for kw in ({}, dict(fix_morph=fix), dict(fix_sed=fix)):
+        exact, generic = run(False, **kw), run(True, **kw)
+        for a, c in zip(exact, generic):
+            np.testing.assert_array_equal(a, c)
+
+
 @pytest.mark.parametrize("B,K,H,W,path", [
     (3, 2, 32, 48, "k_iterate2<4,5> (8 waves per scene)"),
     (5, 4, 24, 64, "k_iterate2<4,5>, short tile"),
