@@ -223,7 +223,8 @@ typedef struct scarlet_batch {
     const float *diff_kernel;
     int32_t psf_h, psf_w;
     int32_t diff_kernel_per_scene;
-    /* workspace owned by the caller: scarlet_batch_workspace_bytes() bytes            */
+    /* workspace owned by the caller: scarlet_batch_workspace_bytes() bytes, ZEROED before
+       the first call (it also holds a cache keyed by a magic word)                     */
     void *workspace;
 } scarlet_batch;
 

@@ -43,7 +43,12 @@ struct FusedArgs {
     const double *centroid_psf; int centroid_P;
     double e_rel2;
     long long *stamps;               // NULL, or [S][16] shader-clock stamps (diagnostics only)
+    float *kscache;                  // NULL, or [S][K][2][SC_KSC_FLOATS]: Hankel vectors of the last k-space symmetry (k_iterate2)
 };
+// Per component and wave of its pair: 64 entries of av, bv, cv (this wave's half), then the header
+// {H W cy cx, magic, dy (2 words), dx (2 words), s} the vectors were made for
+#define SC_KSC_FLOATS 200
+#define SC_KSC_MAGIC 0x5ca71e70u
 
 template <int KM, int BM>
 __global__ __launch_bounds__(SC_BLOCK, 2) void k_iterate(FusedArgs a)

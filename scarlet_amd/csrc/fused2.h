@@ -115,6 +115,18 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
 #define STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)s * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
     const unsigned fl_req = ks_request_lengths(tid);
+    // The Hankel vectors of the k-space symmetry depend on (H, W, centre, shift) only; the shift moves
+    // every fifth iteration and the centre rarely, so each wave keeps its half of the vectors of the
+    // previous iteration in the workspace and recomputes them (float64 sincospi, ~4k cycles on the
+    // constraint chain) only when that key changed.  Requested here, under everything else.
+    float *kcache = nullptr;
+    float kc_v[3] = {0.f, 0.f, 0.f};
+    unsigned kc_hdr = 0;
+    if (a.kscache && (wid >> 1) < K) {
+        kcache = a.kscache + ((size_t)(s * K + (wid >> 1)) * 2 + (wid & 1)) * SC_KSC_FLOATS;
+        kc_v[0] = kcache[lane]; kc_v[1] = kcache[64 + lane]; kc_v[2] = kcache[128 + lane];
+        kc_hdr = reinterpret_cast<const unsigned *>(kcache)[192 + (lane & 7)];
+    }
 
     // ---------------- phase 0: issue every global load, tiles -> LDS, Gram
     float4 mreg[GPT][KM];
@@ -365,7 +377,23 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
             mode = (dy != dy) ? 2 : (sw.centered ? 0 : 1);
             if (mode == 1) {
                 kg = ks_geom(sw, fl_s);
-                sy = pair_ks_vectors(kg, dy, dx, vec, half);
+                const unsigned key[6] = {(unsigned)H << 24 | (unsigned)W << 16 | (unsigned)cy << 8 | (unsigned)cx, SC_KSC_MAGIC,
+                                         (unsigned)__double2loint(dy), (unsigned)__double2hiint(dy),
+                                         (unsigned)__double2loint(dx), (unsigned)__double2hiint(dx)};
+                bool hit = kcache != nullptr;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) hit = hit && (unsigned)__builtin_amdgcn_readlane((int)kc_hdr, i) == key[i];
+                if (hit) {
+                    const int q = lane + SC_WAVE * half;
+                    vec[q] = kc_v[0]; vec[128 + q] = kc_v[1]; vec[256 + q] = kc_v[2];
+                    sy = __int_as_float(__builtin_amdgcn_readlane((int)kc_hdr, 6));
+                } else {
+                    sy = pair_ks_vectors(kg, dy, dx, vec, half, kc_v);
+                    if (kcache) {
+                        kcache[lane] = kc_v[0]; kcache[64 + lane] = kc_v[1]; kcache[128 + lane] = kc_v[2];
+                        if (lane < 7) reinterpret_cast<unsigned *>(kcache)[192 + lane] = lane < 6 ? key[lane] : __float_as_uint(sy);
+                    }
+                }
                 rank1 = sy != 0.f;
                 if (rank1) pair_ks_colsums(t, sw, kg, zv);
             }

@@ -653,13 +653,19 @@ static int64_t gscratch_bytes(const scarlet_batch *b)
     if (update_lds_bytes(b->H, b->W) <= 80 * 1024) return 0;      // two workgroups per CU already
     return align256(sizeof(float) * (int64_t)b->S * b->K * round16(b->H) * scratch_stride(round16(b->W)));
 }
+// cache of the k-space symmetry's Hankel vectors (k_iterate2, fused2.h); zero = empty (no magic word)
+static int64_t kscache_bytes(const scarlet_batch *b)
+{
+    if (b->K > 4 || b->B > 5 || b->H > 64 || b->W > 64) return 0;
+    return align256(sizeof(float) * (int64_t)b->S * b->K * 2 * SC_KSC_FLOATS);
+}
 static int64_t base_workspace_bytes(const scarlet_batch *b)
 {
     const int64_t P = n_partials(b->K, b->B);
     // K > 8 (bigk.h): one scratch plane set [S][B][HW] for G = w^2 (model - image)
     const int64_t resid = b->K > SC_KMAX ? align256(sizeof(float) * (int64_t)b->S * b->B * b->H * b->W) : 0;
     return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4)) + resid +
-           gscratch_bytes(b) + 256;
+           gscratch_bytes(b) + kscache_bytes(b) + 256;
 }
 struct PsfLayout { int64_t loss, real, spec, khat, total; };
 static PsfLayout psf_layout(const scarlet_batch *b)
@@ -699,6 +705,11 @@ static float *ws_gscratch(const scarlet_batch *b)
 {
     const int64_t resid = b->K > SC_KMAX ? align256(sizeof(float) * (int64_t)b->S * b->B * b->H * b->W) : 0;
     return (float *)((char *)ws_resid(b) + resid);
+}
+
+static float *ws_kscache(const scarlet_batch *b)
+{
+    return kscache_bytes(b) ? (float *)((char *)ws_gscratch(b) + gscratch_bytes(b)) : nullptr;
 }
 
 static GradArgs grad_args(const scarlet_batch *b, int approximate_L, int raw_gradient = 0)
@@ -1057,6 +1068,7 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
     f.symmetric = b->symmetric; f.monotonic = b->monotonic; f.l0_thresh = b->l0_thresh; f.l1_thresh = b->l1_thresh;
     f.centroid_psf = b->centroid_psf; f.centroid_P = b->centroid_P; f.e_rel2 = e_rel * e_rel;
     // diagnostics: SCARLET_STAMPS=1 writes phase stamps into the (otherwise unused) partials area
+    f.kscache = (b->diff_kernel || getenv("SCARLET_NO_KSCACHE")) ? nullptr : ws_kscache(b);
     f.stamps = (getenv("SCARLET_STAMPS") && n_partials(b->K, b->B) >= 16) ? (long long *)ws_partials(b) : nullptr;
     // experiment knob: SCARLET_PAD_LDS=<bytes> lowers the number of co-resident workgroups
     const size_t lds = fused_lds_bytes(b) + (getenv("SCARLET_PAD_LDS") ? (size_t)atoi(getenv("SCARLET_PAD_LDS")) : 0);

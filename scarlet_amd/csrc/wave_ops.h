@@ -348,7 +348,8 @@ __device__ __forceinline__ KsGeom ks_geom(const SymWindow &s)
 
 // Hankel vectors: this wave fills entries q = lane + 64 * half.  Returns s = sin(2 pi dy) / Fy
 // (0 for odd Fy), the coefficient of the rank-1 term.
-__device__ inline float pair_ks_vectors(const KsGeom &g, double dy, double dx, float *vec, int half)
+__device__ inline float pair_ks_vectors(const KsGeom &g, double dy, double dx, float *vec, int half,
+                                        float *made = nullptr)
 {
     float *av = vec, *bv = vec + 128, *cv = vec + 256;
     // float64 only where the cancellation lives (the arguments and sin/cos); the final quotients
@@ -381,6 +382,7 @@ __device__ inline float pair_ks_vectors(const KsGeom &g, double dy, double dx, f
         }
     }
     av[q] = va; bv[q] = vb; cv[q] = vc;
+    if (made) { made[0] = va; made[1] = vb; made[2] = vc; }
     return (g.Fy & 1) ? 0.f : (float)(s2y * iFy);
 }
 

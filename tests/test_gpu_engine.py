@@ -165,6 +165,13 @@ def test_exact_shape_instance_is_bit_identical_to_the_generic_kernel(BB, monkeyp
         exact, generic = run(False, **kw), run(True, **kw)
         for a, c in zip(exact, generic):
             np.testing.assert_array_equal(a, c)
+    # the Hankel-vector cache of the k-space symmetry (workspace; vectors are recomputed only when
+    # centre or shift changed) returns exactly what a fresh evaluation gives
+    monkeypatch.setenv("SCARLET_NO_KSCACHE", "1")
+    uncached = run(False)
+    monkeypatch.delenv("SCARLET_NO_KSCACHE")
+    for a, c in zip(uncached, run(False)):
+        np.testing.assert_array_equal(a, c)
 
 
 @pytest.mark.parametrize("B,K,H,W,path", [
