@@ -119,10 +119,19 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     // every fifth iteration and the centre rarely, so each wave keeps its half of the vectors of the
     // previous iteration in the workspace and recomputes them (float64 sincospi, ~4k cycles on the
     // constraint chain) only when that key changed.  Requested here, under everything else.
+    // centre and shift of this pair's component: requested here as well (they are read again only
+    // after the gradient step; a load at that point would put an HBM round trip on the constraint chain)
+    int pre_cy = 0, pre_cx = 0;
+    double pre_dy = 0, pre_dx = 0;
+    if (X && (wid >> 1) < K) {                  // (the generic instance has no registers to spare: it loads late)
+        const int cpre = s * K + (wid >> 1);
+        pre_cy = a.centers[2 * cpre]; pre_cx = a.centers[2 * cpre + 1];
+        pre_dy = a.shifts[2 * cpre]; pre_dx = a.shifts[2 * cpre + 1];
+    }
     float *kcache = nullptr;
     float kc_v[3] = {0.f, 0.f, 0.f};
     unsigned kc_hdr = 0;
-    if (a.kscache && (wid >> 1) < K) {
+    if (X && a.kscache && (wid >> 1) < K) {
         kcache = a.kscache + ((size_t)(s * K + (wid >> 1)) * 2 + (wid & 1)) * SC_KSC_FLOATS;
         kc_v[0] = kcache[lane]; kc_v[1] = kcache[64 + lane]; kc_v[2] = kcache[128 + lane];
         kc_hdr = reinterpret_cast<const unsigned *>(kcache)[192 + (lane & 7)];
@@ -362,11 +371,11 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     float sy = 0.f;
     bool rank1 = false;
     if (mine) {
-        cy = a.centers[2 * c]; cx = a.centers[2 * c + 1];
+        cy = X ? pre_cy : a.centers[2 * c]; cx = X ? pre_cx : a.centers[2 * c + 1];
         wave_max_pixel(t, cy, cx, stat);            // both waves of the pair, identically
         cy = uniform(cy); cx = uniform(cx);
         if (symmetric) {
-            double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
+            double dy = X ? pre_dy : a.shifts[2 * c], dx = X ? pre_dx : a.shifts[2 * c + 1];
             if (it_new % 5 == 0) {
                 // (the partner recomputes the same values: whatever it read from a.shifts is overwritten)
                 wave_centroid(t, a.centroid_psf, a.centroid_P, cy, cx, dy, dx, stat);
@@ -391,7 +400,10 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
                     sy = pair_ks_vectors(kg, dy, dx, vec, half, kc_v);
                     if (kcache) {
                         kcache[lane] = kc_v[0]; kcache[64 + lane] = kc_v[1]; kcache[128 + lane] = kc_v[2];
-                        if (lane < 7) reinterpret_cast<unsigned *>(kcache)[192 + lane] = lane < 6 ? key[lane] : __float_as_uint(sy);
+                        unsigned word = __float_as_uint(sy);           // header word of this lane (selects: no private array)
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) word = lane == i ? key[i] : word;
+                        if (lane < 7) reinterpret_cast<unsigned *>(kcache)[192 + lane] = word;
                     }
                 }
                 rank1 = sy != 0.f;

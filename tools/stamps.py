@@ -13,7 +13,7 @@ b = BlendBatch(imgs, cen, **kw)
 b.init_extended(np.ones(5) * .1)
 b.fit(3, e_rel=0, check_every=0)
 torch.cuda.synchronize()
-b.workspace.zero_()
+b.workspace[:S * 16 * 8].zero_()
 b.fit(1, e_rel=0, check_every=0)
 torch.cuda.synchronize()
 st = b.workspace[:S * 16 * 8].view(torch.int64).view(S, 16).cpu().numpy()
