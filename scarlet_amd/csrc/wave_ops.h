@@ -215,6 +215,10 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         st.p += w.step; st.fa = fa + (T)1;
         return q;
     };
+    // keeps a prepared level where it was written: without it the compiler sinks the preparation
+    // below the early-exit branch, i.e. behind the finish of the level before, and its ~15 lane
+    // instructions land on the store -> load critical path instead of under the LDS reads
+    auto pin = [&](const Prep &q) { asm volatile("" ::"v"(q.p), "v"(q.c1), "v"(q.c2), "v"(q.c3)); };
     auto load = [&](const Prep &q, const Walker<T> &w) {
         Vals v;
         v.x0 = m[q.p]; v.x2 = m[q.p + w.sa]; v.x1 = m[q.p + w.off1];
@@ -252,20 +256,22 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
             {   // odd level
                 const Vals va = load(pa, c1);
                 na = prepare(s0, c0);                           // (no active pixel beyond Lall)
+                pin(na);
                 const bool fa = finish(pa, va, c1);
                 wave_sync();
                 if (early) {
-                    quiet = __any(fa) ? 0 : quiet + 1;
+                    quiet = __builtin_amdgcn_ballot_w64(fa) ? 0 : quiet + 1;
                     if (quiet >= 3) { done = ell; stop = true; break; }
                 }
             }
             if (ell + 1 <= Lc) {   // even level
                 const Vals va = load(na, c0);
                 pa = prepare(s1, c1);
+                pin(pa);
                 const bool fa = finish(na, va, c0);
                 wave_sync();
                 if (early) {
-                    quiet = __any(fa) ? 0 : quiet + 1;
+                    quiet = __builtin_amdgcn_ballot_w64(fa) ? 0 : quiet + 1;
                     if (quiet >= 3) { done = ell + 1; stop = true; break; }
                 }
             }
@@ -287,22 +293,24 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
             {   // odd level
                 const Vals va = load(pa, wx1), vb = load(pb, wy1);
                 na = prepare(sx0, wx0); nb = prepare(sy0, wy0);
+                pin(na); pin(nb);
                 const bool fa = finish(pa, va, wx1);
                 const bool fb = finish(pb, vb, wy1);
                 wave_sync();
                 if (early) {
-                    quiet = __any(fa || fb) ? 0 : quiet + 1;
+                    quiet = __builtin_amdgcn_ballot_w64(fa || fb) ? 0 : quiet + 1;
                     if (quiet >= 3) { done = ell; break; }
                 }
             }
             if (ell + 1 <= Lall) {   // even level
                 const Vals va = load(na, wx0), vb = load(nb, wy0);
                 pa = prepare(sx1, wx1); pb = prepare(sy1, wy1);
+                pin(pa); pin(pb);
                 const bool fa = finish(na, va, wx0);
                 const bool fb = finish(nb, vb, wy0);
                 wave_sync();
                 if (early) {
-                    quiet = __any(fa || fb) ? 0 : quiet + 1;
+                    quiet = __builtin_amdgcn_ballot_w64(fa || fb) ? 0 : quiet + 1;
                     if (quiet >= 3) { done = ell + 1; break; }
                 }
             }
