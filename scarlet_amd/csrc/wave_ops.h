@@ -104,6 +104,18 @@ __device__ inline void wave_centroid(const Tile &t, const double *__restrict__ p
 // right+left wedges in one trip and the down+up wedges in a second; the four neighbour
 // addresses are constant offsets from the walker's own address.
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // <= 1 ulp
+// x * c with 0 * anything == 0 (v_mul_legacy_f32): an unused neighbour has weight 0 and was read from a
+// dummy address (possibly NaN / inf), so the legacy product replaces a compare + select per neighbour;
+// for c > 0 it is the IEEE product
+__device__ __forceinline__ float mul_or_zero(float x, float c)
+{
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(c));
+    return r;
+}
+__device__ __forceinline__ double mul_or_zero(double x, double c) { return c > 0 ? x * c : 0.0; }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 
 // Per-lane walker: everything that does not change along a walk (one per wedge and level
@@ -200,14 +212,19 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     // One level = prepare (addresses and weights: lane arithmetic only) -> load (five LDS reads)
     // -> finish (cap, conditional store).  The level's critical path is store -> load -> finish,
     // so the NEXT level is prepared while this level's reads are in flight.
-    struct Prep { int p; bool act; T c1, c2, c3; };
+    typedef __attribute__((address_space(3))) T LdsT;
+    const unsigned mb = (unsigned)(uintptr_t)m;          // the tile lives in LDS (every caller's does): its LDS byte
+                                                         // address is the low word of the generic pointer
+    struct Prep { unsigned p, p1, p2, p3, p4; bool act; T c1, c2, c3; };     // LDS byte addresses of the pixel and its neighbours
     struct Vals { T x0, x1, x2, x3, x4; };
     // weights of this use from the running state, then one step outwards
     auto prepare = [&](WalkState<T> &st, const Walker<T> &w) {
         Prep q;
         const T fa = st.fa;
         q.act = fa >= w.famin && fa <= w.flim;
-        q.p = q.act ? st.p : psafe;
+        q.p = mb + (unsigned)sizeof(T) * (unsigned)(q.act ? st.p : psafe);
+        q.p2 = q.p + (unsigned)sizeof(T) * (unsigned)w.sa; q.p1 = q.p + (unsigned)sizeof(T) * (unsigned)w.off1;
+        q.p3 = q.p + (unsigned)sizeof(T) * (unsigned)w.off3; q.p4 = q.p + (unsigned)sizeof(T) * (unsigned)w.off4;
         const T t1 = fa + w.fb1, t3 = fa - w.fb3;                 // a + b, a - b (exact small integers)
         q.c1 = t1 > (T)1.5 ? t1 * R2 : (T)0;
         q.c2 = fa;
@@ -218,21 +235,21 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     // keeps a prepared level where it was written: without it the compiler sinks the preparation
     // below the early-exit branch, i.e. behind the finish of the level before, and its ~15 lane
     // instructions land on the store -> load critical path instead of under the LDS reads
-    auto pin = [&](const Prep &q) { asm volatile("" ::"v"(q.p), "v"(q.c1), "v"(q.c2), "v"(q.c3)); };
+    auto pin = [&](const Prep &q) {
+        asm volatile("" ::"v"(q.p), "v"(q.p1), "v"(q.p2), "v"(q.p3), "v"(q.p4), "v"(q.c1), "v"(q.c2), "v"(q.c3));
+    };
     auto load = [&](const Prep &q, const Walker<T> &w) {
         Vals v;
-        v.x0 = m[q.p]; v.x2 = m[q.p + w.sa]; v.x1 = m[q.p + w.off1];
-        v.x3 = m[q.p + w.off3]; v.x4 = m[q.p + w.off4];
+        v.x0 = *(LdsT *)q.p; v.x2 = *(LdsT *)q.p2; v.x1 = *(LdsT *)q.p1; v.x3 = *(LdsT *)q.p3; v.x4 = *(LdsT *)q.p4;
         return v;
     };
     auto finish = [&](const Prep &q, const Vals &v, const Walker<T> &w) {
         const T inv = fast_rcp(q.c1 + q.c2 + q.c3 + w.c4);
         // unused neighbours were read from a dummy address: mask them (0 * NaN != 0)
-        const T t1 = q.c1 > 0 ? v.x1 * q.c1 : (T)0, t3 = q.c3 > 0 ? v.x3 * q.c3 : (T)0;
-        const T t4 = w.c4 > 0 ? v.x4 * w.c4 : (T)0;
-        const T cap = ((v.x2 * q.c2 + t1) + (t3 + t4)) * inv * one_minus;
+        const T t1 = mul_or_zero(v.x1, q.c1), t3 = mul_or_zero(v.x3, q.c3), t4 = mul_or_zero(v.x4, w.c4);
+        const T cap = (fma_t(v.x2, q.c2, t1) + (t3 + t4)) * inv * one_minus;
         const bool lower = q.act && cap < v.x0;
-        if (lower) m[q.p] = cap;
+        if (lower) *(LdsT *)q.p = cap;
         return q.act && (lower ? cap : v.x0) > (T)0;          // does this pixel end up positive?
     };
     // Early exit (only when the caller applies positivity afterwards, as the source pipeline
