@@ -179,7 +179,9 @@ def main():
     # the fused iteration has two variants (scarlet_hip.hip launch_fused); name the one that ran
     kernel_label = KERNEL_NAMES[dom]
     if dom == 4:
-        kernel_label = "k_iterate2<4,5>" if (K <= 4 and B <= 5 and not os.environ.get("SCARLET_FUSED_V1")) else "k_iterate"
+        kernel_label = "k_iterate2<4,5,0>" if (K <= 4 and B <= 5 and not os.environ.get("SCARLET_FUSED_V1")) else "k_iterate"
+        if kernel_label.startswith("k_iterate2") and (K, B, H, W) == (4, 5, 64, 64) and not os.environ.get("SCARLET_NO_EXACT"):
+            kernel_label = "k_iterate2<4,5,64>"        # the exact-shape instance (default pipeline, unit weights)
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes" if args.traffic_bytes else None
     if traffic is None:
         import glob

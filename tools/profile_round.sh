@@ -7,8 +7,8 @@ set -e
 TAG=${1:-r01_c}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o out --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
-cp $(find $R/gpurun_out/prof_$TAG -name '*kernel_stats.csv' | head -1) $R/gpurun_out/${TAG}_kernel_stats_bench_10steps.csv
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o out --output-format csv -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
+cp $(find $R/gpurun_out/prof_$TAG -name '*kernel_stats.csv' | head -1) $R/gpurun_out/${TAG}_kernel_stats_bench_50steps.csv
 grep "^{\"metric\"" $R/gpurun_out/prof_${TAG}_bench.log > $R/gpurun_out/${TAG}_bench_under_rocprof.json || true
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_${TAG}_$c -o out --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
@@ -39,5 +39,5 @@ out = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv 
 json.dump(out, open(R + "/gpurun_out/%s_pmc_traffic_k_iterate.json" % tag, "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("kernel", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}))
 PY
-head -5 $R/gpurun_out/${TAG}_kernel_stats_bench_10steps.csv
+head -5 $R/gpurun_out/${TAG}_kernel_stats_bench_50steps.csv
 cat $R/gpurun_out/${TAG}_bench_under_rocprof.json | cut -c1-300
