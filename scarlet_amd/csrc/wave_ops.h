@@ -114,6 +114,8 @@ __device__ __forceinline__ float mul_or_zero(float x, float c)
     return r;
 }
 __device__ __forceinline__ double mul_or_zero(double x, double c) { return c > 0 ? x * c : 0.0; }
+__device__ __forceinline__ unsigned long long positive_lanes(float v) { return __builtin_amdgcn_fcmpf(v, 0.f, 2 /* FCMP_OGT */); }
+__device__ __forceinline__ unsigned long long positive_lanes(double v) { return __builtin_amdgcn_fcmp(v, 0.0, 2 /* FCMP_OGT */); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
@@ -250,7 +252,8 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         const T cap = (fma_t(v.x2, q.c2, t1) + (t3 + t4)) * inv * one_minus;
         const bool lower = q.act && cap < v.x0;
         if (lower) *(LdsT *)q.p = cap;
-        return q.act && (lower ? cap : v.x0) > (T)0;          // does this pixel end up positive?
+        // lanes whose pixel ends up positive, as a lane mask straight from the compare (idle lanes count as -1)
+        return positive_lanes(q.act ? (lower ? cap : v.x0) : (T)-1);
     };
     // Early exit (only when the caller applies positivity afterwards, as the source pipeline
     // does, and 0 <= thresh <= 1): every closer neighbour of a level-l pixel lies on levels
@@ -259,7 +262,8 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     // zeroed by prox_plus anyway -- the remaining levels need not be swept.  *last_level
     // receives the last level that was computed; the caller zeroes everything beyond it.
     const bool early = last_level != nullptr && thresh >= (T)0 && thresh <= (T)1;
-    int quiet = 0, done = 1 << 30;               // 1 << 30: swept to the end
+    int quiet = 0;                               // consecutive levels without a positive value
+    int done = 1 << 30;                          // 1 << 30: swept to the end
     int ell = 1;
     bool stop = false;
     {   // ---- levels 1 .. 46: one trip per level
@@ -268,29 +272,28 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         WalkState<T> s0 = walk_from(c0, 2), s1 = walk_from(c1, 1);
         const int Lc = min(Lall, SC_COMPACT_LAST);
         Prep pa = prepare(s1, c1);
-        for (; ell <= Lc; ell += 2) {
+        while (ell <= Lc) {
             Prep na;
             {   // odd level
                 const Vals va = load(pa, c1);
                 na = prepare(s0, c0);                           // (no active pixel beyond Lall)
                 pin(na);
-                const bool fa = finish(pa, va, c1);
+                const unsigned long long pm = finish(pa, va, c1);
                 wave_sync();
-                if (early) {
-                    quiet = __builtin_amdgcn_ballot_w64(fa) ? 0 : quiet + 1;
-                    if (quiet >= 3) { done = ell; stop = true; break; }
-                }
+                quiet = pm != 0 ? 0 : quiet + 1;
+                if (early && quiet >= 3) { stop = true; break; }
+                ++ell;
             }
-            if (ell + 1 <= Lc) {   // even level
+            if (ell > Lc) break;
+            {   // even level
                 const Vals va = load(na, c0);
                 pa = prepare(s1, c1);
                 pin(pa);
-                const bool fa = finish(na, va, c0);
+                const unsigned long long pm = finish(na, va, c0);
                 wave_sync();
-                if (early) {
-                    quiet = __builtin_amdgcn_ballot_w64(fa) ? 0 : quiet + 1;
-                    if (quiet >= 3) { done = ell + 1; stop = true; break; }
-                }
+                quiet = pm != 0 ? 0 : quiet + 1;
+                if (early && quiet >= 3) { stop = true; break; }
+                ++ell;
             }
         }
     }
@@ -305,34 +308,32 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         WalkState<T> sx0 = walk_from(wx0, ell + 1), sx1 = walk_from(wx1, ell);
         WalkState<T> sy0 = walk_from(wy0, ell + 1), sy1 = walk_from(wy1, ell);
         Prep pa = prepare(sx1, wx1), pb = prepare(sy1, wy1);
-        for (; ell <= Lall; ell += 2) {
+        while (ell <= Lall) {
             Prep na, nb;
             {   // odd level
                 const Vals va = load(pa, wx1), vb = load(pb, wy1);
                 na = prepare(sx0, wx0); nb = prepare(sy0, wy0);
                 pin(na); pin(nb);
-                const bool fa = finish(pa, va, wx1);
-                const bool fb = finish(pb, vb, wy1);
+                const unsigned long long pm = finish(pa, va, wx1) | finish(pb, vb, wy1);
                 wave_sync();
-                if (early) {
-                    quiet = __builtin_amdgcn_ballot_w64(fa || fb) ? 0 : quiet + 1;
-                    if (quiet >= 3) { done = ell; break; }
-                }
+                quiet = pm != 0 ? 0 : quiet + 1;
+                if (early && quiet >= 3) { stop = true; break; }
+                ++ell;
             }
-            if (ell + 1 <= Lall) {   // even level
+            if (ell > Lall) break;
+            {   // even level
                 const Vals va = load(na, wx0), vb = load(nb, wy0);
                 pa = prepare(sx1, wx1); pb = prepare(sy1, wy1);
                 pin(pa); pin(pb);
-                const bool fa = finish(na, va, wx0);
-                const bool fb = finish(nb, vb, wy0);
+                const unsigned long long pm = finish(na, va, wx0) | finish(nb, vb, wy0);
                 wave_sync();
-                if (early) {
-                    quiet = __builtin_amdgcn_ballot_w64(fa || fb) ? 0 : quiet + 1;
-                    if (quiet >= 3) { done = ell + 1; break; }
-                }
+                quiet = pm != 0 ? 0 : quiet + 1;
+                if (early && quiet >= 3) { stop = true; break; }
+                ++ell;
             }
         }
     }
+    if (stop) done = ell;                        // the last level that was computed
     if (last_level) *last_level = done;
 }
 
