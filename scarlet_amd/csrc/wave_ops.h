@@ -135,7 +135,7 @@ struct Walker {
     int base, b;                       // p = base + a * step ; a = (level - b) >> 1
 };
 template <typename T>
-struct WalkState { int p; T fa; };     // address and major index of the NEXT use
+struct WalkState { int p; T fa; };     // LDS byte address and major index of the NEXT use
 
 // walker of minor index mi (a row for the x-major wedges, a column for the y-major ones)
 template <typename T>
@@ -170,11 +170,11 @@ __device__ __forceinline__ Walker<T> walker_at(bool xmajor, int mi, int H, int W
 }
 // state of walker w for its use at `level` (level = b mod 2)
 template <typename T>
-__device__ __forceinline__ WalkState<T> walk_from(const Walker<T> &w, int level)
+__device__ __forceinline__ WalkState<T> walk_from(const Walker<T> &w, int level, unsigned mb)
 {
     const int a = (level - w.b) >> 1;
     WalkState<T> st;
-    st.p = w.base + a * w.step;
+    st.p = (int)mb + (int)sizeof(T) * (w.base + a * w.step);         // LDS byte address
     st.fa = (T)a;
     return st;
 }
@@ -210,7 +210,6 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     const int Lall = 2 * max(mxr, myr) + min(mxr, myr);
     const T one_minus = (T)1 - thresh;
     const T R2 = (T)0.70710678118654752440;
-    const int psafe = min(1, H - 1) * LW + min(1, W - 1);       // interior address for idle lanes
     // One level = prepare (addresses and weights: lane arithmetic only) -> load (five LDS reads)
     // -> finish (cap, conditional store).  The level's critical path is store -> load -> finish,
     // so the NEXT level is prepared while this level's reads are in flight.
@@ -224,14 +223,17 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         Prep q;
         const T fa = st.fa;
         q.act = fa >= w.famin && fa <= w.flim;
-        q.p = mb + (unsigned)sizeof(T) * (unsigned)(q.act ? st.p : psafe);
+        // st.p is a running LDS byte address.  An idle lane's addresses may leave the tile or the
+        // workgroup's LDS: it only reads there (out-of-range LDS reads return 0, nothing faults) and its
+        // values are discarded -- no redirection to a safe address needed
+        q.p = (unsigned)st.p;
         q.p2 = q.p + (unsigned)sizeof(T) * (unsigned)w.sa; q.p1 = q.p + (unsigned)sizeof(T) * (unsigned)w.off1;
         q.p3 = q.p + (unsigned)sizeof(T) * (unsigned)w.off3; q.p4 = q.p + (unsigned)sizeof(T) * (unsigned)w.off4;
         const T t1 = fa + w.fb1, t3 = fa - w.fb3;                 // a + b, a - b (exact small integers)
         q.c1 = t1 > (T)1.5 ? t1 * R2 : (T)0;
         q.c2 = fa;
         q.c3 = t3 > (T)1.5 ? t3 * R2 : (T)0;
-        st.p += w.step; st.fa = fa + (T)1;
+        st.p += (int)sizeof(T) * w.step; st.fa = fa + (T)1;
         return q;
     };
     // keeps a prepared level where it was written: without it the compiler sinks the preparation
@@ -269,7 +271,7 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     {   // ---- levels 1 .. 46: one trip per level
         const Walker<T> c0 = make_compact_walker<T>(0, H, W, LW, cy, cx, lane);
         const Walker<T> c1 = make_compact_walker<T>(1, H, W, LW, cy, cx, lane);
-        WalkState<T> s0 = walk_from(c0, 2), s1 = walk_from(c1, 1);
+        WalkState<T> s0 = walk_from(c0, 2, mb), s1 = walk_from(c1, 1, mb);
         const int Lc = min(Lall, SC_COMPACT_LAST);
         Prep pa = prepare(s1, c1);
         while (ell <= Lc) {
@@ -305,8 +307,8 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         const Walker<T> wx1 = make_walker<T>(true, 1, H, W, LW, cy, cx, half, k2);
         const Walker<T> wy0 = make_walker<T>(false, 0, H, W, LW, cy, cx, half, k2);
         const Walker<T> wy1 = make_walker<T>(false, 1, H, W, LW, cy, cx, half, k2);
-        WalkState<T> sx0 = walk_from(wx0, ell + 1), sx1 = walk_from(wx1, ell);
-        WalkState<T> sy0 = walk_from(wy0, ell + 1), sy1 = walk_from(wy1, ell);
+        WalkState<T> sx0 = walk_from(wx0, ell + 1, mb), sx1 = walk_from(wx1, ell, mb);
+        WalkState<T> sy0 = walk_from(wy0, ell + 1, mb), sy1 = walk_from(wy1, ell, mb);
         Prep pa = prepare(sx1, wx1), pb = prepare(sy1, wy1);
         while (ell <= Lall) {
             Prep na, nb;
