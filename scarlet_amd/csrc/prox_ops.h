@@ -120,12 +120,14 @@ __device__ __forceinline__ int sweep_level(int y, int x, int cy, int cx)
 }
 
 // `lastpos` (one int of LDS, or NULL): early exit as in wave_monotonic -- only for callers that
-// apply positivity afterwards, with 0 <= thresh <= 1.  Every thread that leaves a positive
-// value at level l stores l there (all writers of a level store the same value); once three
-// consecutive levels stored nothing, all later pixels end <= 0 and the sweep stops.  Returns
-// the last level swept (1 << 30: all of them); the caller zeroes the pixels beyond it.
+// zero everything <= `floor` afterwards (positivity: floor = 0; the detection cut of the source
+// initialisation: floor = bg_cutoff >= 0), with 0 <= thresh <= 1.  Every thread that leaves a value
+// above the floor at level l stores l there (all writers of a level store the same value); once three
+// consecutive levels stored nothing, all later pixels end <= floor (a cap is a convex combination of
+// closer pixels times 1 - thresh) and the sweep stops.  Returns the last level swept (1 << 30: all
+// of them); the caller zeroes the pixels beyond it.
 template <bool NEAREST, typename T>
-__device__ inline int monotonic_tile(const TileT<T> &t, int cy, int cx, T thresh, int *lastpos = nullptr)
+__device__ inline int monotonic_tile(const TileT<T> &t, int cy, int cx, T thresh, int *lastpos = nullptr, T floor = (T)0)
 {
     if (lastpos) {
         if (threadIdx.x == 0) *lastpos = 0;
@@ -180,7 +182,7 @@ __device__ inline int monotonic_tile(const TileT<T> &t, int cy, int cx, T thresh
             }
             const T cur = m[py * LW + px];
             if (cap < cur) m[py * LW + px] = cap;
-            if (lastpos && (cap < cur ? cap : cur) > (T)0) *lastpos = ell;
+            if (lastpos && (cap < cur ? cap : cur) > floor) *lastpos = ell;
         }
         __syncthreads();
         // (a thread that already runs level ell + 1 may have stored ell + 1: the decision is the same)

@@ -1221,10 +1221,14 @@ __global__ __launch_bounds__(SC_BLOCK) void k_init_extended(InitArgs a, double *
     __syncthreads();
     const SymWindow sw = sym_window(H, W, cy, cx);
     if (a.do_symmetric) flip_symmetry_tile<double>(t, sw, true, 1.0);      // sdss (source.py:162)
-    if (a.do_monotonic) monotonic_tile<false, double>(t, cy, cx, 0.1);     // thresh=.1 (source.py:165-167)
+    // thresh=.1 (source.py:165-167).  Everything <= cutoff is zeroed below (source.py:170-175), so the sweep
+    // may stop once three levels hold nothing above the cutoff: the levels beyond cannot exceed it either
+    __shared__ int lastpos_s;
+    int lstop = 1 << 30;
+    if (a.do_monotonic) lstop = monotonic_tile<false, double>(t, cy, cx, 0.1, cutoff >= 0 ? &lastpos_s : nullptr, cutoff);
     double cnt = 0;
     for (int i = threadIdx.x; i < HW; i += SC_BLOCK)
-        if (t.m[(i / W) * t.LW + (i % W)] > cutoff) cnt += 1;
+        if (t.m[(i / W) * t.LW + (i % W)] > cutoff && sweep_level(i / W, i % W, cy, cx) <= lstop) cnt += 1;
     cnt = block_sum(cnt, red);
     // morph[~mask] = 0 happens BEFORE the centre pixel is read (source.py:174-178)
     const double centre = t.m[cy * t.LW + cx] > cutoff ? t.m[cy * t.LW + cx] : 0.0;
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_init_extended(InitArgs a, double *
     float *gm = a.morph[wbuf] + (size_t)c * HW;
     for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
         const double v = t.m[(i / W) * t.LW + (i % W)];
-        gm[i] = (float)(v > cutoff ? v / centre : 0.0);
+        gm[i] = (float)((v > cutoff && sweep_level(i / W, i % W, cy, cx) <= lstop) ? v / centre : 0.0);
     }
     if (threadIdx.x < B) a.sed[wbuf][(size_t)c * B + threadIdx.x] = sed_s[threadIdx.x];
     if (threadIdx.x == 0) {
