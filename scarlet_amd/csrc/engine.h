@@ -14,6 +14,7 @@
 #pragma once
 #include "common.h"
 #include "prox_ops.h"
+#include "wave_ops.h"
 
 #define SC_TILE_PIX 4096          // pixels per (scene, tile) workgroup in k_grad / k_step
 #define SC_KMAX 8               // register-tiled gradient kernels
@@ -472,6 +473,7 @@ struct UpdateArgs {
     double *conv;                     // [S][K][4]: d2_sed, n2_sed, d2_morph, n2_morph
     int force_it0;                    // 1: constructor call (it = 0, ignore `active`)
     float *gscratch;                  // GT kernels: [S*K][round16(H) * scratch_stride(round16(W))] (T = X B)
+    int hybrid_sweep;                 // LDS tiles: sweep levels 1 .. 46 on one wave (wave_monotonic), the rest on the workgroup
 };
 
 // MODE 0/1: the morphology tile lives in LDS (tiles up to ~128 x 128).
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
     __shared__ double shf[2];
     __shared__ int stat;
     __shared__ int lastpos;
+    __shared__ int hyb[2];
 
     const int c0 = a.cur[s];
     const int wbuf = a.in_iteration ? 1 - c0 : c0;
@@ -557,7 +560,22 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
                       false, 0.f, scr, av, bv, cv, zv, stage, GT);
     }
     int lstop = 1 << 30;          // last sweep level computed (early exit); pixels beyond are <= 0 -> 0
-    if (a.monotonic) lstop = monotonic_tile<false, float>(t, cy, cx, 0.f, &lastpos);   // source.py:436
+    if (a.monotonic) {                                                                   // source.py:436
+        if (!GT && a.hybrid_sweep) {
+            // tile in LDS: levels 1 .. 46 on one wave without barriers (wave_ops.h; a sweep usually stops
+            // before), the rest level-synchronously on the whole workgroup
+            if (threadIdx.x < SC_WAVE) {
+                int done, quiet;
+                wave_monotonic<float>(t, cy, cx, 0.f, &done, &quiet);
+                if (threadIdx.x == 0) { hyb[0] = done; hyb[1] = quiet; }
+            }
+            __syncthreads();
+            lstop = hyb[0];
+            if (lstop == (1 << 30))
+                lstop = monotonic_tile<false, float>(t, cy, cx, 0.f, &lastpos, 0.f, SC_COMPACT_LAST + 1, SC_COMPACT_LAST - hyb[1]);
+        } else
+            lstop = monotonic_tile<false, float>(t, cy, cx, 0.f, &lastpos);
+    }
     if (threadIdx.x == 0) { a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
 
     // sparse_l0 / sparse_l1 (update.py:71-82; config 5), positive (update.py:27-32),
@@ -685,8 +703,6 @@ __global__ void k_converge(int S, int K, const double *conv, int *flags, int *ac
 // ------------------------------------------------------------------------------------
 // k_source_update_w: the same pipeline with one WAVE per component (wave_ops.h), four
 // components per 256-thread workgroup, no workgroup barriers.  H, W <= 64.
-#include "wave_ops.h"
-
 __device__ inline void wave_pipeline(const UpdateArgs &a, int c, float *lds_wave)
 {
     const int s = c / a.K;

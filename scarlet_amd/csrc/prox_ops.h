@@ -127,10 +127,13 @@ __device__ __forceinline__ int sweep_level(int y, int x, int cy, int cx)
 // closer pixels times 1 - thresh) and the sweep stops.  Returns the last level swept (1 << 30: all
 // of them); the caller zeroes the pixels beyond it.
 template <bool NEAREST, typename T>
-__device__ inline int monotonic_tile(const TileT<T> &t, int cy, int cx, T thresh, int *lastpos = nullptr, T floor = (T)0)
+__device__ inline int monotonic_tile(const TileT<T> &t, int cy, int cx, T thresh, int *lastpos = nullptr, T floor = (T)0,
+                                     int ell0 = 1, int lastpos0 = 0)
 {
+    // (ell0, lastpos0): continue a sweep whose levels < ell0 are done, the last one with a value above the
+    // floor being lastpos0
     if (lastpos) {
-        if (threadIdx.x == 0) *lastpos = 0;
+        if (threadIdx.x == 0) *lastpos = lastpos0;
         __syncthreads();
     }
     const int H = t.H, W = t.W, LW = t.LW;
@@ -140,7 +143,7 @@ __device__ inline int monotonic_tile(const TileT<T> &t, int cy, int cx, T thresh
     const T one_minus = (T)1 - thresh;
     const int oct = threadIdx.x & 7;
     const bool sw = oct & 1, fx = oct & 2, fy = oct & 4;
-    for (int ell = 1; ell <= Lmax; ++ell) {
+    for (int ell = ell0; ell <= Lmax; ++ell) {
         const int a0 = (ell + 2) / 3, a1 = ell >> 1;
         for (int a = a0 + (threadIdx.x >> 3); a <= a1; a += (SC_BLOCK >> 3)) {
             const int b = ell - 2 * a;                 // 0 <= b <= a

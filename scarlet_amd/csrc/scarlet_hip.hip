@@ -988,6 +988,7 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
     u.l0_thresh = b->l0_thresh; u.l1_thresh = b->l1_thresh;
     u.centroid_psf = b->centroid_psf; u.centroid_P = b->centroid_P; u.conv = ws_conv(b); u.force_it0 = force_it0;
     u.gscratch = nullptr;
+    u.hybrid_sweep = getenv("SCARLET_NO_HYBRID_SWEEP") ? 0 : 1;
     if (b->H <= 64 && b->W <= 64 && !getenv("SCARLET_FORCE_BLOCK_UPDATE")) {
         // one wave per component, four components per workgroup (wave_ops.h)
         const size_t lds = sizeof(float) * SC_NWAVES * ((size_t)b->H * tile_stride(b->W) + SC_WAVE_VEC_FLOATS);

@@ -200,8 +200,11 @@ __device__ __forceinline__ Walker<T> make_compact_walker(int e, int H, int W, in
     return walker_at<T>(xmajor, mi, H, W, LW, cy, cx, wedge & 1, !(side && b == 0));   // the axis belongs to side 0
 }
 
+// `quiet_out` != NULL: compact levels only (1 .. 46, any tile size); *quiet_out receives the number of
+// trailing levels without a positive value, for a caller that continues the sweep from level 47 itself.
 template <typename T>
-__device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thresh, int *last_level = nullptr)
+__device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thresh, int *last_level = nullptr,
+                                      int *quiet_out = nullptr)
 {
     const int H = t.H, W = t.W, LW = t.LW;
     T *m = t.m;
@@ -299,7 +302,8 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
             }
         }
     }
-    if (!stop && ell <= Lall) {
+    if (quiet_out) *quiet_out = quiet;
+    if (!stop && ell <= Lall && !quiet_out) {
         // ---- levels 47 ..: two trips per level (right/left wedges, then down/up), one walker
         // per 32-lane half and level parity.  (ell == 47 here.)
         const int half = lane >> 5, k2 = (lane & 31) << 1;
