@@ -418,7 +418,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     if (mine && mode == 1) {
         if (rank1) pair_ks_z(kg, vec + 256, zv);
         STAMP(14);
-        pair_ks_gemm1(t, sw, kg, vec, half, T);
+        pair_ks_gemm1<true>(t, sw, kg, vec, half, T);
         STAMP(15);
     }
     if (mine) pair_sync(2);                         // B2: every read of X is done

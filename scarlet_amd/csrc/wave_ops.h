@@ -446,7 +446,10 @@ __device__ inline void pair_ks_z(const KsGeom &g, const float *cv, float *zv)
 // GEMM 1: T[:, tc] = Xw . Hankel(bv)[:, tc] for this wave's column tiles tc = half, half + 2.
 // NTR row tiles x NI column tiles are compile-time (the caller switches on the wave-uniform
 // window size): straight-line MFMA chains, no control flow between them.
-template <int NTR, int NI>
+// PEEL: the operand masking below is compiled only into the fetch of the last k-group (a uniform branch picks
+// the variant); the second code path costs registers in callers that inline both halves of the pair
+// decomposition (wave_kspace_symmetry), so only the pair kernel asks for it.
+template <int NTR, int NI, bool PEEL>
 __device__ __forceinline__ void pair_ks_gemm1_impl(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
                                                    int half, f32x4 (&T)[4][2])
 {
@@ -462,10 +465,11 @@ __device__ __forceinline__ void pair_ks_gemm1_impl(const Tile &t, const SymWindo
         rowp[tr] = t.m + (s.y0 + min((tr << 4) + lr, g.h - 1)) * LW + s.x0 + 4 * lq;
     const float *bp = bv + (half << 4) + lr + 4 * lq;
     struct Ops { float a[NTR][4], b[NI][4]; };
-    auto fetch = [&](int k0) {
+    // columns beyond the window (only in the last group: wp - w < 16) must count as zero
+    auto fetch_as = [&](int k0, auto masked) {
+        constexpr int MASKED = decltype(masked)::value;     // 0: never, 1: always, 2: decided per group at run time
         Ops o;
-        // columns beyond the window (only in the last group: wp - w < 16) must count as zero
-        const bool last = k0 + 16 > g.w;
+        const bool last = MASKED == 1 || (MASKED == 2 && k0 + 16 > g.w);
 #pragma unroll
         for (int tr = 0; tr < NTR; ++tr)
 #pragma unroll
@@ -478,6 +482,11 @@ __device__ __forceinline__ void pair_ks_gemm1_impl(const Tile &t, const SymWindo
 #pragma unroll
             for (int j = 0; j < 4; ++j) o.b[i][j] = bp[k0 + (i << 5) + j];
         return o;
+    };
+    auto fetch = [&](int k0) {
+        if (!PEEL) return fetch_as(k0, std::integral_constant<int, 2>{});
+        if (k0 + 16 > g.w) return fetch_as(k0, std::integral_constant<int, 1>{});
+        return fetch_as(k0, std::integral_constant<int, 0>{});
     };
     auto multiply = [&](const Ops &o) {
 #pragma unroll
@@ -508,6 +517,7 @@ __device__ __forceinline__ void pair_ks_gemm1_impl(const Tile &t, const SymWindo
     }
 }
 
+template <bool PEEL = false>
 __device__ inline void pair_ks_gemm1(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
                                      int half, f32x4 (&T)[4][2])
 {
@@ -517,8 +527,8 @@ __device__ inline void pair_ks_gemm1(const Tile &t, const SymWindow &s, const Ks
         for (int i = 0; i < 2; ++i) T[tr][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ni = half < g.ntc ? (half + 2 < g.ntc ? 2 : 1) : 0;
     if (ni == 0) return;
-#define SC_G1(NTR_) do { if (ni == 2) pair_ks_gemm1_impl<NTR_, 2>(t, s, g, vec, half, T);          \
-                         else pair_ks_gemm1_impl<NTR_, 1>(t, s, g, vec, half, T); } while (0)
+#define SC_G1(NTR_) do { if (ni == 2) pair_ks_gemm1_impl<NTR_, 2, PEEL>(t, s, g, vec, half, T);    \
+                         else pair_ks_gemm1_impl<NTR_, 1, PEEL>(t, s, g, vec, half, T); } while (0)
     switch (g.ntr) { case 1: SC_G1(1); break; case 2: SC_G1(2); break; case 3: SC_G1(3); break; default: SC_G1(4); }
 #undef SC_G1
 }
