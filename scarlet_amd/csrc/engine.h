@@ -484,6 +484,9 @@ struct UpdateArgs {
 //             through LDS in the other variant.
 //   MODE 0 tile + GEMM scratch in LDS;  MODE 1 tile in LDS, scratch in HBM (halves the LDS
 //   footprint of a 128 x 128 frame: two workgroups per CU);  MODE 2 both in HBM (the text above)
+#define SC_BOX_R (SC_COMPACT_LAST / 2)           // levels <= 46 stay within 23 pixels of the peak
+#define SC_BOX_LW (2 * SC_BOX_R + 3)
+#define SC_BOX_FLOATS ((2 * SC_BOX_R + 1) * SC_BOX_LW)
 template <int MODE>
 __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
 {
@@ -568,6 +571,34 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
                 int done, quiet;
                 wave_monotonic<float>(t, cy, cx, 0.f, &done, &quiet);
                 if (threadIdx.x == 0) { hyb[0] = done; hyb[1] = quiet; }
+            }
+            __syncthreads();
+            lstop = hyb[0];
+            if (lstop == (1 << 30))
+                lstop = monotonic_tile<false, float>(t, cy, cx, 0.f, &lastpos, 0.f, SC_COMPACT_LAST + 1, SC_COMPACT_LAST - hyb[1]);
+        } else if (GT && a.hybrid_sweep && stage_floats(hp, wp) >= SC_BOX_FLOATS) {
+            // plane in HBM: the pixels of levels 1 .. 46 (and their closer neighbours) lie within 23 pixels of the
+            // peak -- that box goes to LDS, one wave sweeps it without barriers, the box goes back, and the
+            // workgroup-level sweep on the plane continues from level 47 only if the wave did not stop.  Inside
+            // the box every bounds decision of the walkers coincides with the frame's (b <= 15, a <= 23).
+            float *box = stage;       // free during the sweep; stage_floats >= 16 * 144 >= SC_BOX_FLOATS for every frame that takes this path
+            const int by0 = max(0, cy - SC_BOX_R), bx0 = max(0, cx - SC_BOX_R);
+            const int bh = min(H, cy + SC_BOX_R + 1) - by0, bw = min(W, cx + SC_BOX_R + 1) - bx0;
+            Tile bt; bt.H = bh; bt.W = bw; bt.LW = SC_BOX_LW; bt.m = box;
+            for (int i = threadIdx.x; i < bh * bw; i += SC_BLOCK) {
+                const int y = i / bw, x = i - y * bw;
+                box[y * SC_BOX_LW + x] = t.m[(by0 + y) * t.LW + bx0 + x];
+            }
+            __syncthreads();
+            if (threadIdx.x < SC_WAVE) {
+                int done, quiet;
+                wave_monotonic<float>(bt, cy - by0, cx - bx0, 0.f, &done, &quiet);
+                if (threadIdx.x == 0) { hyb[0] = done; hyb[1] = quiet; }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < bh * bw; i += SC_BLOCK) {
+                const int y = i / bw, x = i - y * bw;
+                t.m[(by0 + y) * t.LW + bx0 + x] = box[y * SC_BOX_LW + x];
             }
             __syncthreads();
             lstop = hyb[0];
