@@ -435,9 +435,17 @@ __device__ inline void pair_ks_z(const KsGeom &g, const float *cv, float *zv)
 {
     const int lane = lane_id();
     wave_sync();
+    // four terms per trip: zv[j2 .. j2 + 3] in two 8-byte broadcast reads, cv in two paired reads.  Same order of
+    // the FMA chain; the up to three extra terms multiply zv = 0 (zv is zero from w on, cv runs into finite
+    // neighbours), which leaves the sum unchanged
     float z = 0.f;
     if (lane < g.w)
-        for (int j2 = 0; j2 < g.w; ++j2) z += cv[lane + j2] * zv[j2];
+        for (int j2 = 0; j2 < g.w; j2 += 4) {
+            const float4 z4 = lds_load4(zv + j2);              // (8-byte aligned for every tile shape, not always 16)
+            const float *cp = cv + lane + j2;
+            z = fma_t(cp[0], z4.x, z); z = fma_t(cp[1], z4.y, z);
+            z = fma_t(cp[2], z4.z, z); z = fma_t(cp[3], z4.w, z);
+        }
     wave_sync();
     zv[lane] = z;
     wave_sync();
