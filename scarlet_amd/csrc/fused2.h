@@ -529,8 +529,9 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (GEN) v[e] = sparse(v[e]);
-                        v[e] = v[e] < 0.f ? 0.f : v[e];                       // NaN stays NaN
-                        if (CUT && (axmax < 0 || (unsigned)(xb + e) > (unsigned)(2 * axmax))) v[e] = 0.f;
+                        // positivity and the sweep's cut in one select (NaN inside the cut stays NaN)
+                        const bool beyond = CUT && (axmax < 0 || (unsigned)(xb + e) > (unsigned)(2 * axmax));
+                        v[e] = (v[e] < 0.f || beyond) ? 0.f : v[e];
                     }
                     f32x2 o01, o23;
                     if (GEN && !regular) {
