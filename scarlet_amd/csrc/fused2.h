@@ -423,7 +423,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     }
     if (mine) pair_sync(2);                         // B2: every read of X is done
     STAMP(13);
-    if (mine && mode == 1) pair_ks_gemm2(t, sw, kg, vec, zv, half, T, sy, rank1);
+    if (mine && mode == 1) pair_ks_gemm2<true>(t, sw, kg, vec, zv, half, T, sy, rank1);
     if (mine && mode == 2 && lead) wave_flip_symmetry<float>(t, sw, false, 1.0f);
     if (mine) pair_sync(3);                         // B3
     STAMP(9);

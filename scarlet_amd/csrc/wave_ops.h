@@ -542,7 +542,9 @@ __device__ inline void pair_ks_gemm1(const Tile &t, const SymWindow &s, const Ks
 }
 
 // GEMM 2 + epilogue in place for this wave's column tiles
-template <int NTR, int NI>
+// PAIR: address arithmetic of the epilogue for the pair kernel (one address per column tile, the last row
+// tile alone checks the bottom edge); the other callers keep the form that costs them fewer registers
+template <int NTR, int NI, bool PAIR>
 __device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
                                                    const float *zv, int half, const f32x4 (&T)[4][2], float sy, bool rank1)
 {
@@ -569,16 +571,24 @@ __device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindo
         float xin[NI][4];
         float *pp[NI][4];
         bool ok[NI][4];
+        const int row0 = (tr << 4) + lq * 4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int jcol = ((half + 2 * i) << 4) + lr;
+            float *p0 = &m[(s.y0 + row0) * LW + s.x0 + jcol];     // one address per column tile, rows at + r LW
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = (tr << 4) + lq * 4 + r;
-                ok[i][r] = row < g.h && jcol < g.w;
+                const int row = row0 + r;
                 // lanes outside the window combine a dummy slot (the B vector is dead after GEMM 1):
                 // no branches between the MFMA chains
-                pp[i][r] = ok[i][r] ? &m[(s.y0 + row) * LW + s.x0 + jcol] : dummy;
+                if (PAIR) {
+                    // only the last row tile can leave the window at the bottom (h > 16 (NTR - 1))
+                    ok[i][r] = (tr < NTR - 1 || row < g.h) && jcol < g.w;
+                    pp[i][r] = ok[i][r] ? p0 + r * LW : dummy;
+                } else {
+                    ok[i][r] = row < g.h && jcol < g.w;
+                    pp[i][r] = ok[i][r] ? &m[(s.y0 + row) * LW + s.x0 + jcol] : dummy;
+                }
                 xin[i][r] = *pp[i][r];
             }
         }
@@ -603,13 +613,14 @@ __device__ __forceinline__ void pair_ks_gemm2_impl(const Tile &t, const SymWindo
     }
 }
 
+template <bool PAIR = false>
 __device__ inline void pair_ks_gemm2(const Tile &t, const SymWindow &s, const KsGeom &g, const float *vec,
                                      const float *zv, int half, const f32x4 (&T)[4][2], float sy, bool rank1)
 {
     const int ni = half < g.ntc ? (half + 2 < g.ntc ? 2 : 1) : 0;
     if (ni == 0) return;
-#define SC_G2(NTR_) do { if (ni == 2) pair_ks_gemm2_impl<NTR_, 2>(t, s, g, vec, zv, half, T, sy, rank1);   \
-                         else pair_ks_gemm2_impl<NTR_, 1>(t, s, g, vec, zv, half, T, sy, rank1); } while (0)
+#define SC_G2(NTR_) do { if (ni == 2) pair_ks_gemm2_impl<NTR_, 2, PAIR>(t, s, g, vec, zv, half, T, sy, rank1);   \
+                         else pair_ks_gemm2_impl<NTR_, 1, PAIR>(t, s, g, vec, zv, half, T, sy, rank1); } while (0)
     switch (g.ntr) { case 1: SC_G2(1); break; case 2: SC_G2(2); break; case 3: SC_G2(3); break; default: SC_G2(4); }
 #undef SC_G2
 }
