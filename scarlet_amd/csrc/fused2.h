@@ -79,6 +79,7 @@ template <int KM, int BM, int XS = 0>
 __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
 {
     static_assert(KM <= 4, "one pair of waves per component");
+    static_assert(1 + KM * BM <= 32 && 4 * SC_NW2 == 32, "the partial sums are combined by 32 rows of 16 lanes");
     constexpr bool X = XS > 0;
     extern __shared__ __align__(16) float lds[];
     const int s = blockIdx.x;
@@ -209,14 +210,20 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     // Lipschitz constants (blend.py:205-218): L_sed = lambda_max(S S^T) on lane 0,
     // L_morph = lambda_max(A^T A) on lane 1 of wave 0 -- one instruction stream for both
     if (wid == 0) {
-        if (lane < K * K) {
-            const int k = lane / K, k2 = lane - k * K;
+        {   // the 4 x 8 row partials of every Gram entry: lane = 4 entry + q adds eight of them, the four
+            // lanes of a quad combine (K * K <= 16 entries on the 64 lanes)
+            const int e = lane >> 2, q = lane & 3;
+            const int k = e / K, k2 = e - k * K;
             const int lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
             const int go = lo * KM - (lo * (lo - 1)) / 2 + (hi - lo);    // packed upper-triangle index (KM x KM)
             double r = 0;
+            if (e < K * K) {
 #pragma unroll
-            for (int w = 0; w < 4 * SC_NW2; ++w) r += (double)red[w][go];
-            mat[0][k * KM + k2] = r;
+                for (int w = 0; w < SC_NW2; ++w) r += (double)red[q * SC_NW2 + w][go];
+            }
+            r += dpp_mov<SC_DPP_XOR1>(r);
+            r += dpp_mov<SC_DPP_XOR2>(r);
+            if (e < K * K && q == 0) mat[0][k * KM + k2] = r;
         }
         if (lane < (small_side ? K * K : B * B)) {
             double r = 0;
@@ -324,12 +331,17 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     }
     __syncthreads();
     STAMP(3);
-    for (int i = tid; i < 1 + K * B; i += SC_FB2) {
-        const int src = i == 0 ? 0 : 1 + ((i - 1) / B) * BM + (i - 1) % B;     // (k, b) of the K x B list in the KM x BM layout
-        double r = 0;
-#pragma unroll
-        for (int w = 0; w < 4 * SC_NW2; ++w) r += (double)red[w][src];
-        tot[i] = r;
+    {   // the 4 x 8 row partials of the loss and of every SED-gradient entry: one 16-lane row per entry, two
+        // partials per lane, the row combines (1 + K B <= 32 entries on the 512 threads)
+        const int i = tid >> 4, p = tid & 15;
+        const bool live = i < 1 + K * B;
+        const int src = (!live || i == 0) ? 0 : 1 + ((i - 1) / B) * BM + (i - 1) % B;   // (k, b) of the K x B list in the KM x BM layout
+        double r = live ? (double)red[p][src] + (double)red[p + 16][src] : 0.0;
+        r += dpp_mov<SC_DPP_XOR1>(r);
+        r += dpp_mov<SC_DPP_XOR2>(r);
+        r += dpp_mov<SC_DPP_HALF_MIRROR>(r);
+        r += dpp_mov<SC_DPP_MIRROR>(r);
+        if (live && p == 0) tot[i] = r;
     }
     __syncthreads();
     for (int i = tid; i < K * B; i += SC_FB2) {
