@@ -94,7 +94,6 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     constexpr int GPT = 2;                       // float4 groups per thread in phases 0/1 (H, W <= 64)
     constexpr int GPW = 8;                       // float4 groups per lane in the pair's final pass
     __shared__ float red[4 * SC_NW2][NP > NG ? NP : NG];  // partial sums per 16-lane row of every wave
-    __shared__ double tot[NP > NG ? NP : NG];
     __shared__ double mat[2][KM * KM > BM * BM ? KM * KM : BM * BM];
     __shared__ float sed_s[KM * BM], sed_new[KM * BM];
     __shared__ float step_s[2];
@@ -341,16 +340,18 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         r += dpp_mov<SC_DPP_XOR2>(r);
         r += dpp_mov<SC_DPP_HALF_MIRROR>(r);
         r += dpp_mov<SC_DPP_MIRROR>(r);
-        if (live && p == 0) tot[i] = r;
+        // the lane that holds an entry's total takes the SED step (blend.py:91-93) / stores the loss (blend.py:138)
+        if (live && p == 0) {
+            if (i == 0) {
+                if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = r;
+            } else {
+                const int k = (i - 1) / B, b = (i - 1) - k * B;
+                const float curv = sed_s[k * BM + b];
+                const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + k];
+                sed_new[k * BM + b] = fixed ? curv : curv - step_sed * (float)r;
+            }
+        }
     }
-    __syncthreads();
-    for (int i = tid; i < K * B; i += SC_FB2) {
-        const int k = i / B, b = i - k * B;
-        const float curv = sed_s[k * BM + b];
-        const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + k];
-        sed_new[k * BM + b] = fixed ? curv : curv - step_sed * (float)tot[1 + i];
-    }
-    if (tid == 0 && it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = tot[0];
     __syncthreads();
     STAMP(4);
 
