@@ -83,7 +83,11 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     constexpr bool X = XS > 0;
     extern __shared__ __align__(16) float lds[];
     const int s = blockIdx.x;
-    if (!a.active[s]) return;
+    // the three per-scene words are requested together (one scalar round trip, not three in a row), and both
+    // buffer pointers come from fixed kernel-argument offsets (an index into a.morph[] would be a fourth)
+    const int active_s = a.active[s], c0 = a.cur[s], it_old = a.it[s];
+    asm volatile("" ::"s"(c0), "s"(it_old));     // (keeps the two loads above the branch: the compiler sinks them otherwise)
+    if (!active_s) return;
     const int K = X ? KM : a.K, B = X ? BM : a.B, H = X ? XS : a.H, W = X ? XS : a.W, HW = H * W, LW = tile_stride(W);
     const int tile_floats = H * LW;
     const bool symmetric = X ? true : a.symmetric != 0, monotonic = X ? true : a.monotonic != 0;
@@ -103,12 +107,12 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     __shared__ int pair_flag[KM][2];           // phase counters of the pair-local synchronisation
     __shared__ unsigned short fl_s[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wid = uniform(tid >> 6);    // wid in an SGPR: scalar branches
-    const int c0 = a.cur[s];
-    const float *min_g = a.morph[c0] + (size_t)s * K * HW;
-    float *mout_g = a.morph[1 - c0] + (size_t)s * K * HW;
-    const float *sed_in = a.sed[c0] + (size_t)s * K * B;
-    float *sed_out = a.sed[1 - c0] + (size_t)s * K * B;
-    const int it_new = a.it[s] + 1;
+    float *const morph0 = a.morph[0], *const morph1 = a.morph[1], *const sed0 = a.sed[0], *const sed1 = a.sed[1];
+    const float *min_g = (c0 ? morph1 : morph0) + (size_t)s * K * HW;
+    float *mout_g = (c0 ? morph0 : morph1) + (size_t)s * K * HW;
+    const float *sed_in = (c0 ? sed1 : sed0) + (size_t)s * K * B;
+    float *sed_out = (c0 ? sed0 : sed1) + (size_t)s * K * B;
+    const int it_new = it_old + 1;
     const int ngroups = HW >> 2, gpr = W >> 2;           // float4 groups, groups per row
     const float *img = a.images + (size_t)s * B * HW;
     const float *wgt = (!X && a.weights) ? a.weights + (size_t)s * B * HW : nullptr;
@@ -617,13 +621,16 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         if (it_new > 1) {
             bool done = true;
             for (int kk = 0; kk < K; ++kk) {
-                int f = a.flags[s * K + kk];
+                // the two convergence bits are rewritten whatever they were, the other bits stay: posted
+                // atomics instead of load - modify - store (a load here would put an HBM round trip at the
+                // very end of the workgroup, with its LDS and registers still held)
+                int set = 0;
                 const double d2 = conv_m[kk][0][0] + conv_m[kk][1][0], n2 = conv_m[kk][0][1] + conv_m[kk][1][1];
-                if (n2 == n2 && conv_s[kk][0] <= a.e_rel2 * conv_s[kk][1]) f &= ~SCARLET_FLAG_SED_NOT_CONVERGED;
-                else { f |= SCARLET_FLAG_SED_NOT_CONVERGED; done = false; }
-                if (d2 <= a.e_rel2 * n2) f &= ~SCARLET_FLAG_MORPH_NOT_CONVERGED;
-                else { f |= SCARLET_FLAG_MORPH_NOT_CONVERGED; done = false; }
-                a.flags[s * K + kk] = f;
+                if (!(n2 == n2 && conv_s[kk][0] <= a.e_rel2 * conv_s[kk][1])) { set |= SCARLET_FLAG_SED_NOT_CONVERGED; done = false; }
+                if (!(d2 <= a.e_rel2 * n2)) { set |= SCARLET_FLAG_MORPH_NOT_CONVERGED; done = false; }
+                const int clear = (SCARLET_FLAG_SED_NOT_CONVERGED | SCARLET_FLAG_MORPH_NOT_CONVERGED) & ~set;
+                if (clear) atomicAnd(&a.flags[s * K + kk], ~clear);
+                if (set) atomicOr(&a.flags[s * K + kk], set);
             }
             if (done) a.active[s] = 0;
         }
