@@ -369,11 +369,15 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     // publishes the phase it has completed (after a release fence on its LDS writes) and sleeps until
     // its partner has published the same phase.  The four components then run their chains
     // independently; the workgroup meets again at the end of phase 2.
-    auto pair_sync = [&](int phase) {
+    // LONG: the wait for the partner's sweep (~15k cycles): poll every 512 cycles instead of every 128 -- a poll
+    // is four instructions taken from the SIMD's other waves
+    auto pair_sync = [&](int phase, auto long_wait) {
+        constexpr bool LONG = decltype(long_wait)::value;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(&pair_flag[k & (KM - 1)][half], phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(&pair_flag[k & (KM - 1)][1 - half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase)
-            __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(&pair_flag[k & (KM - 1)][1 - half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase) {
+            if (LONG) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(2);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     const bool mine = k < K;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         }
     }
     STAMP(8);
-    if (mine) pair_sync(1);                         // B1: Hankel vectors complete
+    if (mine) pair_sync(1, std::false_type{});                         // B1: Hankel vectors complete
     STAMP(12);
     f32x4 T[4][2];
     if (mine && mode == 1) {
@@ -438,11 +442,11 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         pair_ks_gemm1<true>(t, sw, kg, vec, half, T);
         STAMP(15);
     }
-    if (mine) pair_sync(2);                         // B2: every read of X is done
+    if (mine) pair_sync(2, std::false_type{});                         // B2: every read of X is done
     STAMP(13);
     if (mine && mode == 1) pair_ks_gemm2<true>(t, sw, kg, vec, zv, half, T, sy, rank1);
     if (mine && mode == 2 && lead) wave_flip_symmetry<float>(t, sw, false, 1.0f);
-    if (mine) pair_sync(3);                         // B3
+    if (mine) pair_sync(3, std::false_type{});                         // B3
     STAMP(9);
     // lane -> (row, float4 group) walk of the final pass without divisions: +128 groups per step
     const int dyq = (2 * SC_WAVE) / gpr, dxq = 2 * SC_WAVE - dyq * gpr;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         if (lane == 0) { lstop_s[k] = lstop; a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
         load_last();
     }
-    if (mine) pair_sync(4);                         // B4: sweep done, lstop published
+    if (mine) pair_sync(4, std::true_type{});                         // B4: sweep done, lstop published
     STAMP(10);
     // ---- sparsity, positivity (update.py:71-82, 27-32), normalisation (update.py:62-65),
     // store, convergence sums: one pass over the LDS tile, float4 groups split between the pair
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
             if (__any(anynan)) vmax = __builtin_nanf("");
             if (lane == 0) nmax_s[k][half] = vmax;
         }
-        if (mine) pair_sync(5);
+        if (mine) pair_sync(5, std::false_type{});
         if (mine) {
             const float m0 = nmax_s[k][0], m1 = nmax_s[k][1];
             norm = (m0 != m0 || m1 != m1) ? __builtin_nanf("") : fmaxf(m0, m1);
