@@ -1178,6 +1178,7 @@ struct InitArgs {
     int has_scale;
     int do_symmetric, do_monotonic;
     double thresh;
+    int no_hybrid;                    // diagnostics: SCARLET_NO_HYBRID_SWEEP
 };
 
 // GT: frames whose float64 tile does not fit LDS work on a tile in a temporary HBM buffer
@@ -1226,7 +1227,23 @@ __global__ __launch_bounds__(SC_BLOCK) void k_init_extended(InitArgs a, double *
     // may stop once three levels hold nothing above the cutoff: the levels beyond cannot exceed it either
     __shared__ int lastpos_s;
     int lstop = 1 << 30;
-    if (a.do_monotonic) lstop = monotonic_tile<false, double>(t, cy, cx, 0.1, cutoff >= 0 ? &lastpos_s : nullptr, cutoff);
+    if (a.do_monotonic) {
+        if (!GT && cutoff >= 0 && !a.no_hybrid) {
+            // levels 1 .. 46 on one wave without barriers (wave_ops.h), the rest on the workgroup if needed
+            __shared__ int hyb[2];
+            if (threadIdx.x < SC_WAVE) {
+                int done, quiet;
+                wave_monotonic<double>(t, cy, cx, 0.1, &done, &quiet, cutoff);
+                if (threadIdx.x == 0) { hyb[0] = done; hyb[1] = quiet; }
+            }
+            __syncthreads();
+            lstop = hyb[0];
+            if (lstop == (1 << 30))
+                lstop = monotonic_tile<false, double>(t, cy, cx, 0.1, &lastpos_s, cutoff, SC_COMPACT_LAST + 1,
+                                                      SC_COMPACT_LAST - hyb[1]);
+        } else
+            lstop = monotonic_tile<false, double>(t, cy, cx, 0.1, cutoff >= 0 ? &lastpos_s : nullptr, cutoff);
+    }
     double cnt = 0;
     for (int i = threadIdx.x; i < HW; i += SC_BLOCK)
         if (t.m[(i / W) * t.LW + (i % W)] > cutoff && sweep_level(i / W, i % W, cy, cx) <= lstop) cnt += 1;
@@ -1260,6 +1277,7 @@ extern "C" int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host,
     a.morph[0] = b->morph[0]; a.morph[1] = b->morph[1]; a.cur = b->cur; a.centers = b->centers; a.flags = b->flags;
     a.has_scale = sed_scale_host != nullptr; a.thresh = thresh;
     a.do_symmetric = init_symmetric; a.do_monotonic = init_monotonic;
+    a.no_hybrid = getenv("SCARLET_NO_HYBRID_SWEEP") ? 1 : 0;
     for (int i = 0; i < SC_BMAX; ++i) {
         a.bg_rms[i] = i < b->B ? (double)bg_rms_host[i] : 1.0;
         a.sed_scale[i] = (i < b->B && sed_scale_host) ? (double)sed_scale_host[i] : 1.0;

@@ -202,9 +202,11 @@ __device__ __forceinline__ Walker<T> make_compact_walker(int e, int H, int W, in
 
 // `quiet_out` != NULL: compact levels only (1 .. 46, any tile size); *quiet_out receives the number of
 // trailing levels without a positive value, for a caller that continues the sweep from level 47 itself.
+// `floor`: the early exit counts values above it (0: the caller applies positivity; the detection cut of the
+// source initialisation, which zeroes everything <= cut).
 template <typename T>
 __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thresh, int *last_level = nullptr,
-                                      int *quiet_out = nullptr)
+                                      int *quiet_out = nullptr, T floor = (T)0)
 {
     const int H = t.H, W = t.W, LW = t.LW;
     T *m = t.m;
@@ -258,7 +260,7 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         const bool lower = q.act && cap < v.x0;
         if (lower) *(LdsT *)q.p = cap;
         // lanes whose pixel ends up positive, as a lane mask straight from the compare (idle lanes count as -1)
-        return positive_lanes(q.act ? (lower ? cap : v.x0) : (T)-1);
+        return positive_lanes(q.act ? (lower ? cap : v.x0) - floor : (T)-1);
     };
     // Early exit (only when the caller applies positivity afterwards, as the source pipeline
     // does, and 0 <= thresh <= 1): every closer neighbour of a level-l pixel lies on levels
