@@ -155,8 +155,8 @@ int scarlet_cut_below(float *x, int64_t count, double thresh, void *stream);
  * x > min_value (inclusive bounds); {H, -1, W, -1} when no pixel qualifies. */
 int scarlet_trim(const float *x, int n, int H, int W, float min_value, int32_t *box, void *stream);
 /* interpolation.fft_resample (interpolation.py:408-448) as used by update.translation
- * (update.py:159-167), n planes [H][W], out of place: separable taps [n][2][8] float64 (ky, kx:
- * ny / nx of them used), first tap positions win0 [n][2] int32 (the kernels' window[0]). */
+ * (update.py:159-167), n planes [H][W], out of place: separable taps [n][2][12] float64 (ky, kx:
+ * ny / nx <= 12 of them used), first tap positions win0 [n][2] int32 (the kernels' window[0]). */
 int scarlet_resample(const float *in, float *out, int n, int H, int W, const double *taps,
                      const int32_t *win0, int ny, int nx, void *stream);
 

@@ -875,6 +875,35 @@ def bilinear(dx):
     return np.array([-dx, 1 + dx]), np.array([-1, 0])
 
 
+def cubic_spline(dx, a=1, b=0):
+    """interpolation.cubic_spline (interpolation.py:168-213): piecewise cubic on |x| <= 1 and 1 < |x| < 2."""
+    if np.abs(dx) > 1:
+        raise ValueError("The fractional shift dx must be between -1 and 1")
+    window = np.arange(-1, 3) + np.floor(dx)
+    x = np.abs(dx - window)
+    out = np.zeros(4)
+    for i, v in enumerate(x):
+        if v <= 1:
+            out[i] = ((-6 * a - 9 * b + 12) * v ** 3 + (6 * a + 12 * b - 18) * v ** 2 + (-2 * b + 6)) / 6
+        elif v < 2:
+            out[i] = ((-6 * a - b) * v ** 3 + (30 * a + 6 * b) * v ** 2 + (-48 * a - 12 * b) * v + (24 * a + 8 * b)) / 6
+    return out, window.astype(int)
+
+
+def quintic_spline(dx):
+    """interpolation.quintic_spline (interpolation.py:255-270), window -3 .. 3."""
+    window = np.arange(-3, 4)
+    out = np.zeros(7)
+    for i, v in enumerate(np.abs(dx - window)):
+        if v <= 1:
+            out[i] = 1 + v ** 3 / 12 * (-95 + 138 * v - 55 * v ** 2)
+        elif v <= 2:
+            out[i] = (v - 1) * (v - 2) / 24 * (-138 + 348 * v - 249 * v ** 2 + 55 * v ** 3)
+        elif v <= 3:
+            out[i] = (v - 2) * (v - 3) ** 2 / 24 * (-54 + 50 * v - 11 * v ** 2)
+    return out, window
+
+
 def _project(image, shape, yx0=None):
     """interpolation.project_image (interpolation.py:6-84): place `image` in zeros(shape) with its
     first pixel at shape//2 + yx0 (yx0 = -(image.shape//2) when None), clipped at the borders."""
@@ -891,12 +920,12 @@ def _project(image, shape, yx0=None):
     return out
 
 
-def fft_resample(img, dy, dx, kernel=lanczos):
+def fft_resample(img, dy, dx, kernel=lanczos, **kwargs):
     """interpolation.fft_resample (interpolation.py:408-448) with fft_convolve (:114-136):
     circular convolution of the zero-padded image with the separable kernel, both ifftshift-ed,
     the real part fftshift-ed back and cropped to the image."""
-    ky, ywin = kernel(dy)
-    kx, xwin = kernel(dx)
+    ky, ywin = kernel(dy, **kwargs)
+    kx, xwin = kernel(dx, **kwargs)
     k2 = np.outer(ky, kx)
     shape = (img.shape[0] + k2.shape[0] + 3, img.shape[1] + k2.shape[1] + 3)
     K = _project(k2, shape, (ywin[0], xwin[0]))

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_trim(const float *x, int H, int W,
 // reference pads by kernel size + 3 before its circular FFT product, more than the taps reach, so
 //   out[y][x] = sum_i sum_j ky[i] kx[j] in[y - (y0 + i)][x - (x0 + j)]   (zero outside the image)
 // with y0/x0 the first tap positions (window[0]).  Accumulated in float64.
-// taps [n][2][SC_TAPS_MAX] float64 (ky then kx), win0 [n][2] int32
-#define SC_TAPS_MAX 8
+// taps [n][2][SC_TAPS_MAX] float64 (ky then kx; Lanczos-5 has ten), win0 [n][2] int32
+#define SC_TAPS_MAX 12
 __global__ __launch_bounds__(SC_BLOCK) void k_resample(const float *in, float *out, int H, int W,
                                                          const double *taps, const int32_t *win0, int ny, int nx)
 {

@@ -391,7 +391,7 @@ extern "C" int scarlet_resample(const float *in, float *out, int n, int H, int W
     if (n < 0 || H <= 0 || W <= 0 || !in || !out || in == out || !taps || !win0)
         return set_err(SCARLET_E_ARG, "bad resample arguments");
     if (ny < 1 || nx < 1 || ny > SC_TAPS_MAX || nx > SC_TAPS_MAX)
-        return set_err(SCARLET_E_ARG, "resampling kernels have 1 to 8 taps");
+        return set_err(SCARLET_E_ARG, "resampling kernels have 1 to 12 taps");
     if (n == 0) return SCARLET_OK;
     int bx = (H * W + SC_BLOCK - 1) / SC_BLOCK;
     if (bx > 256) bx = 256;

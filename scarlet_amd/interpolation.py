@@ -27,6 +27,40 @@ def lanczos(dx, a=3):
     return y, window.astype(int)
 
 
+def cubic_spline(dx, a=1, b=0):
+    """Four-tap cubic (Mitchell-Netravali family, sharpness a, shape b) at floor(dx) + (-1 .. 2)
+    (reference interpolation.py:168-213)."""
+    if np.abs(dx) > 1:
+        raise ValueError("The fractional shift dx must be between -1 and 1")
+    window = np.arange(-1, 3) + np.floor(dx)
+    x = np.abs(dx - window)
+    near = ((12 - 6 * a - 9 * b) * x ** 3 + (6 * a + 12 * b - 18) * x ** 2 + (6 - 2 * b)) / 6        # |x| <= 1
+    far = ((-6 * a - b) * x ** 3 + (30 * a + 6 * b) * x ** 2 - (48 * a + 12 * b) * x + (24 * a + 8 * b)) / 6   # 1 < |x| < 2
+    y = np.where(x <= 1, near, np.where(x < 2, far, 0.0))
+    return y, window.astype(int)
+
+
+def catmull_rom(dx):
+    """cubic_spline with a = 1/2, b = 0 (reference interpolation.py:216-221)."""
+    return cubic_spline(dx, a=.5, b=0)
+
+
+def mitchel_netravali(dx):
+    """cubic_spline with a = b = 1/3 (reference interpolation.py:224-230)."""
+    return cubic_spline(dx, a=1 / 3, b=1 / 3)
+
+
+def quintic_spline(dx, dtype=np.float64):
+    """Seven-tap quintic spline on the fixed window -3 .. 3 (reference interpolation.py:255-270)."""
+    window = np.arange(-3, 4)
+    x = np.abs(dx - window).astype(dtype)
+    inner = 1 + x ** 3 / 12 * (-95 + 138 * x - 55 * x ** 2)
+    middle = (x - 1) * (x - 2) / 24 * (-138 + 348 * x - 249 * x ** 2 + 55 * x ** 3)
+    outer = (x - 2) * (x - 3) ** 2 / 24 * (-54 + 50 * x - 11 * x ** 2)
+    y = np.where(x <= 1, inner, np.where(x <= 2, middle, np.where(x <= 3, outer, 0.0)))
+    return y, window
+
+
 def get_separable_kernel(dy, dx, kernel=lanczos, **kwargs):
     """2-D kernel = outer(ky, kx) with its pixel windows (reference interpolation.py:273-299)."""
     kx, x_window = kernel(dx, **kwargs)
@@ -40,9 +74,9 @@ def fft_resample(img, dy, dx, kernel=lanczos, **kwargs):
     torch = _lib.require_gpu()
     kx, xwin = kernel(dx, **kwargs)
     ky, ywin = kernel(dy, **kwargs)
-    if len(ky) > 8 or len(kx) > 8:
-        raise ValueError("resampling kernels have at most 8 taps")
-    taps = np.zeros((1, 2, 8), dtype=np.float64)
+    if len(ky) > 12 or len(kx) > 12:
+        raise ValueError("resampling kernels have at most 12 taps")
+    taps = np.zeros((1, 2, 12), dtype=np.float64)
     taps[0, 0, :len(ky)] = ky
     taps[0, 1, :len(kx)] = kx
     win0 = np.array([[int(ywin[0]), int(xwin[0])]], dtype=np.int32)

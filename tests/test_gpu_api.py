@@ -489,3 +489,25 @@ def test_translation_matches_the_reference(scarlet):
         assert rel_err(res, g[key]) < 1e-6
     with pytest.raises(ValueError):
         scarlet.interpolation.lanczos(1.5)
+
+
+def test_resample_with_every_kernel_vs_oracle(scarlet):
+    """interpolation.fft_resample with each separable kernel of the reference (bilinear, cubic spline family,
+    Lanczos 3 and 5, quintic spline: 2 to 10 taps) against the oracle's FFT form (oracle/pgm.py
+    fft_resample, itself pinned on reference-generated fixtures); float32 planes: 1e-6 max-norm relative."""
+    from oracle import pgm
+    I = scarlet.interpolation
+    rng = np.random.RandomState(5)
+    img = rng.rand(29, 34) - 0.1
+    cases = [(I.bilinear, pgm.bilinear, {}), (I.cubic_spline, pgm.cubic_spline, {}),
+             (I.catmull_rom, pgm.cubic_spline, dict(a=.5, b=0)),
+             (I.mitchel_netravali, pgm.cubic_spline, dict(a=1 / 3, b=1 / 3)),
+             (I.lanczos, pgm.lanczos, {}), (I.lanczos, pgm.lanczos, dict(a=5)),
+             (I.quintic_spline, pgm.quintic_spline, {})]
+    for kern, okern, okw in cases:
+        kw = okw if kern in (I.lanczos, I.cubic_spline) else {}
+        for dy, dx in ((.31, -.47), (-.9, .05)):
+            got = I.fft_resample(img, dy, dx, kernel=kern, **kw)
+            want = pgm.fft_resample(img, dy, dx, kernel=okern, **okw)
+            assert got.shape == img.shape
+            assert rel_err(got, want) < 1e-6, (kern.__name__, okw, dy, dx)

@@ -135,3 +135,45 @@ def test_scene_npz_loader(tmp_path):
     # the fixture copied from the reference's hsc_cosmos_35 file (catalog stored as an (K, 2) array)
     h = io.load_scene(os.path.join(os.path.dirname(__file__), "golden", "hsc_inputs.npz"))
     assert h["images"].shape == (5, 58, 48) and h["psfs"].shape == (5, 43, 43) and h["centers"].shape == (7, 2)
+
+
+def test_interpolation_kernels_reference_vectors():
+    """The separable resampling kernels against the golden vectors of the reference's
+    tests/test_interpolation.py:216-330 (bilinear, cubic spline and its two named cases, Lanczos 3 and 5,
+    the separable 2-D kernel); the oracle's restatement against the same vectors."""
+    import scarlet_amd.interpolation as I
+    from oracle import pgm
+    from numpy.testing import assert_almost_equal, assert_array_equal
+
+    def compare(func, zero_truth, positive_truth, **kw):
+        r = func(0, **kw)
+        assert_almost_equal(r[0], zero_truth[0]); assert_array_equal(r[1], zero_truth[1])
+        r = func(.103, **kw)
+        assert_almost_equal(r[0], positive_truth[0]); assert_array_equal(r[1], positive_truth[1])
+        r = func(-.103, **kw)      # the mirrored kernel on the mirrored window
+        assert_almost_equal(r[0], positive_truth[0][::-1]); assert_array_equal(r[1], -np.asarray(positive_truth[1])[::-1])
+        with pytest.raises(ValueError):
+            func(1.1, **kw)
+
+    cubic = (np.array([-0.08287473, 0.97987473, 0.11251627, -0.00951627]), np.array([-1, 0, 1, 2]))
+    lz3 = (np.array([0.01763955, -0.07267534, 0.98073579, 0.09695747, -0.0245699, 0.00123974]), np.arange(6) - 2)
+    lz5 = (np.array([5.11187895e-03, -1.55432491e-02, 3.52955166e-02, -8.45895745e-02, 9.81954247e-01,
+                     1.06954413e-01, -4.15882547e-02, 1.85994926e-02, -6.77652513e-03, 4.34415682e-04]), np.arange(10) - 4)
+    z5 = np.zeros(10); z5[4] = 1
+    for mod in (I, pgm):
+        # (bilinear's window depends on the sign of the shift: (0, 1) or (-1, 0), interpolation.py:139-165)
+        r = mod.bilinear(0); assert_almost_equal(r[0], [1, 0]); assert_array_equal(r[1], [0, 1])
+        r = mod.bilinear(.103); assert_almost_equal(r[0], [1 - .103, .103]); assert_array_equal(r[1], [0, 1])
+        r = mod.bilinear(-.103); assert_almost_equal(r[0], [.103, 1 - .103]); assert_array_equal(r[1], [-1, 0])
+        compare(mod.cubic_spline, (np.array([0., 1., 0., 0.]), np.array([-1, 0, 1, 2])), cubic)
+        compare(mod.lanczos, (np.array([0, 0, 1, 0, 0, 0]), np.arange(6) - 2), lz3)
+        compare(mod.lanczos, (z5, np.arange(10) - 4), lz5, a=5)
+    compare(I.catmull_rom, I.cubic_spline(0, a=.5), I.cubic_spline(.103, a=.5))
+    compare(I.mitchel_netravali, I.cubic_spline(0, a=1 / 3, b=1 / 3), I.cubic_spline(.103, a=1 / 3, b=1 / 3))
+    q, w = I.quintic_spline(.2)
+    assert_almost_equal(q, pgm.quintic_spline(.2)[0]); assert_array_equal(w, np.arange(-3, 4))
+    assert abs(q.sum() - 1) < 1e-12                         # partition of unity
+    k2, yw, xw = I.get_separable_kernel(.103, .42)
+    truth_row2 = [0.028138304, -0.142694735, 0.696941621, 0.489860766, -0.115257837, 0.018469518]
+    assert_almost_equal(k2[2], truth_row2)
+    assert_array_equal(yw, [-2, -1, 0, 1, 2, 3]); assert_array_equal(xw, [-2, -1, 0, 1, 2, 3])
