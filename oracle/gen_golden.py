@@ -393,6 +393,33 @@ def gen_fit_extras2(sc):
     save("fit_extras2", **out)
 
 
+def gen_fit_extras3(sc):
+    """CombinedExtendedSource / init_combined_extended_source (source.py:183-240, 495-536): SED over the channels
+    of all observations, morphology from the detection coadd of observation `obs_idx`; no update() in the
+    constructor, symmetric=False by default.  Two band-sliced observations, 6 iterations."""
+    out = {}
+    scn = synth.make_scene(7)
+    images = scn["images"]
+    ch = list("grizy")
+    frame = sc.Frame(images.shape, dtype=np.float32, channels=ch)
+    obs = [sc.Observation(images[:3], channels=ch[:3]).match(frame),
+           sc.Observation(images[3:], channels=ch[3:]).match(frame)]
+    cen = [tuple(int(v) for v in p) for p in scn["centers"]]
+    bg = [np.ones(3) * 0.1, np.ones(2) * 0.1]
+    for idx in (0, 1):
+        srcs = [sc.CombinedExtendedSource(frame, p, obs, bg, obs_idx=idx) for p in cen]
+        out["init%d_sed" % idx] = np.array([c.sed for c in srcs])
+        out["init%d_morph" % idx] = np.array([c.morph for c in srcs])
+        if idx == 0:
+            blend = sc.Blend(srcs, obs)
+            blend.fit(6, e_rel=0)
+            out["sed"] = np.array([c.sed for c in blend.components])
+            out["morph"] = np.array([c.morph for c in blend.components])
+            out["mse"] = np.array(blend.mse)
+            out["center"] = np.array([c.pixel_center for c in blend.components]).astype(np.int64)
+    save("fit_extras3", **out)
+
+
 def gen_thresh_translate(sc):
     """update.threshold / measurement.threshold (log-histogram noise cut) and update.translation
     (Lanczos resampling by component.shift): SURVEY.md 8f rank 3, off the default pipeline."""
@@ -460,6 +487,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "extras2":
         gen_fit_extras2(sc)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "extras3":
+        gen_fit_extras3(sc)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "extras":
         gen_fit_extras(sc)
         return
@@ -476,6 +506,7 @@ def main():
     sc.interpolation = scarlet.interpolation
     gen_thresh_translate(sc)
     gen_fit_extras2(sc)
+    gen_fit_extras3(sc)
 
 
 if __name__ == "__main__":

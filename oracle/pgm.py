@@ -617,6 +617,16 @@ def init_extended_source(pixel, images, bg_rms, obs_psfs=None, frame_psf=None, t
     return sed, morph
 
 
+def init_combined_extended_source(pixel, images_list, bg_rms_list, obs_idx=0, thresh=1., symmetric=True,
+                                  monotonic=True):
+    """source.init_combined_extended_source (source.py:183-240), observations without PSFs: the SED runs over
+    the channels of all observations, the morphology comes from observation `obs_idx` alone."""
+    sed = np.concatenate([psf_sed(im, pixel) for im in images_list])
+    _, morph = init_extended_source(pixel, images_list[obs_idx], bg_rms_list[obs_idx], None, None, thresh,
+                                    symmetric, monotonic)
+    return sed, morph
+
+
 # -------------------------------------------------------------------------- blend.py
 class Scene(object):
     """One blend: data + sources.  Mirrors Blend + one matched Observation."""

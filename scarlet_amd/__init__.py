@@ -17,7 +17,8 @@ from .update import (positive_sed, positive_morph, positive, normalized, sparse_
                      threshold, monotonic, translation, symmetric)
 from .component import BlendFlag, Prior, Component, ComponentTree
 from .source import (SourceInitError, get_pixel_sed, get_psf_sed, get_best_fit_seds,
-                     build_detection_coadd, init_extended_source, init_multicomponent_source, PointSource,
+                     build_detection_coadd, init_extended_source, init_combined_extended_source,
+                     init_multicomponent_source, PointSource, CombinedExtendedSource,
                      ExtendedSource, MultiComponentSource, RandomSource)
 from .observation import Frame, Observation
 from .blend import Blend

@@ -193,6 +193,43 @@ class ExtendedSource(PointSource):
         self.update()
 
 
+def init_combined_extended_source(sky_coord, frame, observations, bg_rms, obs_idx=0, thresh=1.,
+                                  symmetric=True, monotonic=True):
+    """(sed, morph) for a source seen by several observations (reference source.py:183-240): the SED is
+    the concatenation of the per-observation PSF-scaled SEDs, the morphology comes from the detection
+    coadd of observation `obs_idx` (device initialisation, as for ExtendedSource)."""
+    import torch
+    try:
+        iter(observations)
+    except TypeError:
+        observations = [observations]
+    seds = [torch.as_tensor(_host(get_psf_sed(sky_coord, obs, frame))).reshape(-1) for obs in observations]
+    sed = torch.cat(seds).to(device="cuda", dtype=torch.float32)
+    if bool((sed <= 0).any()):
+        msg = "Zero or negative SED {} at y={}, x={}".format(sed.cpu().numpy(), *sky_coord)
+        (logger.warning if bool((sed <= 0).all()) else logger.info)(msg)
+    b, _ = _device_init(sky_coord, frame, observations[obs_idx], bg_rms[obs_idx], thresh, symmetric, monotonic)
+    return sed, b.morph[0][0, 0].clone()
+
+
+class CombinedExtendedSource(PointSource):
+    """Extended source initialised to match a set of observations (reference source.py:495-536).  As in the
+    reference the constructor does not run update(), `symmetric` defaults to False and the initial
+    morphology is always made symmetric."""
+
+    def __init__(self, frame, sky_coord, observations, bg_rms, obs_idx=0, thresh=1, symmetric=False,
+                 monotonic=True, center_step=5, delay_thresh=0, **component_kwargs):
+        self.symmetric = symmetric
+        self.monotonic = monotonic
+        self.coords = sky_coord
+        self.pixel_center = frame.get_pixel(sky_coord)
+        self.center_step = center_step
+        self.delay_thresh = delay_thresh
+        sed, morph = init_combined_extended_source(sky_coord, frame, observations, bg_rms, obs_idx, thresh,
+                                                   True, monotonic)
+        Component.__init__(self, frame, sed, morph, **component_kwargs)
+
+
 def init_multicomponent_source(sky_coord, frame, observation, bg_rms, flux_percentiles=None,
                                thresh=1., symmetric=True, monotonic=True):
     """(seds, morphs) of a source split into layered components at the given flux percentiles

@@ -511,3 +511,33 @@ def test_resample_with_every_kernel_vs_oracle(scarlet):
             want = pgm.fft_resample(img, dy, dx, kernel=okern, **okw)
             assert got.shape == img.shape
             assert rel_err(got, want) < 1e-6, (kern.__name__, okw, dy, dx)
+
+
+def test_combined_extended_source_matches_the_reference(scarlet):
+    """CombinedExtendedSource / init_combined_extended_source (reference source.py:183-240, 495-536) on two
+    band-sliced observations: initial factors for obs_idx = 0 and 1 and a 6-iteration fit, against a fixture
+    generated by the reference (gen_fit_extras3).  The sources have symmetric=False and their constructor
+    runs no update(), as in the reference."""
+    from scarlet_amd import synth
+    g = load_golden("fit_extras3")
+    scn = synth.make_scene(7)
+    images = scn["images"]
+    ch = list("grizy")
+    frame = scarlet.Frame(images.shape, channels=ch)
+    obs = [scarlet.Observation(images[:3], channels=ch[:3]).match(frame),
+           scarlet.Observation(images[3:], channels=ch[3:]).match(frame)]
+    cen = [tuple(int(v) for v in p) for p in scn["centers"]]
+    bg = [np.ones(3) * 0.1, np.ones(2) * 0.1]
+    for idx in (0, 1):
+        srcs = [scarlet.CombinedExtendedSource(frame, p, obs, bg, obs_idx=idx) for p in cen]
+        assert srcs[0].symmetric is False
+        assert rel_err(np.array([npy(c.sed) for c in srcs]), g["init%d_sed" % idx]) < 1e-6
+        assert rel_err(np.array([npy(c.morph) for c in srcs]), g["init%d_morph" % idx]) < 1e-5
+    srcs = [scarlet.CombinedExtendedSource(frame, p, obs, bg, obs_idx=0) for p in cen]
+    blend = scarlet.Blend(srcs, obs)
+    blend.fit(6, e_rel=0)
+    assert blend.it == 6
+    assert rel_err(blend.mse, g["mse"]) < 1e-5
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["morph"]) < 2e-5
+    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["sed"]) < 2e-5
+    assert_array_equal(np.array([c.pixel_center for c in blend.components]), g["center"])

@@ -513,3 +513,29 @@ def test_translation_fixture_and_reference_bilinear_case():
         truth[2 + sy:8 + sy, 2:8] += _img * (1 - Dx) * Dy
         truth[2 + sy:8 + sy, 2 + sx:8 + sx] += _img * Dx * Dy
         assert_almost_equal(res, truth)
+
+
+def test_fit_extras3_fixture_combined_extended_source():
+    """CombinedExtendedSource (source.py:183-240, 495-536) on two band-sliced observations: initial factors for
+    obs_idx = 0 and 1, and a 6-iteration fit (sources without symmetry, no update() in the constructor);
+    reference-generated."""
+    g = load_golden("fit_extras3")
+    scn = synth.make_scene(7)
+    images = scn["images"]
+    parts = [images[:3], images[3:]]
+    bgs = [np.ones(3) * 0.1, np.ones(2) * 0.1]
+    for idx in (0, 1):
+        init = [pgm.init_combined_extended_source(tuple(int(v) for v in p), parts, bgs, obs_idx=idx)
+                for p in scn["centers"]]
+        assert rel_err(np.array([i[0] for i in init]), g["init%d_sed" % idx]) < 1e-6
+        assert rel_err(np.array([i[1] for i in init]), g["init%d_morph" % idx]) < 1e-6
+    init = [pgm.init_combined_extended_source(tuple(int(v) for v in p), parts, bgs, obs_idx=0) for p in scn["centers"]]
+    sc = pgm.scene_from_state(images, [i[0] for i in init], [i[1] for i in init], scn["centers"], None)
+    for s in sc.sources:
+        s.symmetric = False
+    sc.observations = [dict(images=images[:3], band_slice=slice(0, 3)), dict(images=images[3:], band_slice=slice(3, 5))]
+    pgm.fit(sc, 6, e_rel=0)
+    assert rel_err(sc.mse, g["mse"]) < 1e-5
+    assert rel_err(np.array([c.morph for c in sc.sources]), g["morph"]) < 2e-5
+    assert rel_err(np.array([c.sed for c in sc.sources]), g["sed"]) < 2e-5
+    assert_array_equal(np.array([c.center for c in sc.sources]), g["center"])
