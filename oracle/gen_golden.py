@@ -420,6 +420,26 @@ def gen_fit_extras3(sc):
     save("fit_extras3", **out)
 
 
+def gen_geometry(sc):
+    """Host-side geometry helpers of operator.py that the reference's tests do not pin: diagonalizeArray
+    (481-522) and getRadialMonotonicWeights in nearest mode (540-621)."""
+    import scarlet.operator as rop
+    out = {}
+    arr = np.arange(20.).reshape(4, 5) + 1
+    d, m = rop.diagonalizeArray(arr)
+    out["diag_in"] = arr; out["diag"] = d; out["diag_mask"] = m
+    d, m = rop.diagonalizeArray(arr.reshape(-1), shape=(4, 5))
+    out["diag_flat"] = d
+    cases = [((5, 5), (2, 2), 1), ((7, 6), (1, 4), 1), ((9, 9), None, 0.5)]
+    for n, (shape, c, mg) in enumerate(cases):
+        sc.cache.Cache._cache = {}
+        out["near%d" % n] = rop.getRadialMonotonicWeights(shape, useNearest=True, minGradient=mg, center=c)
+        out["near%d_shape" % n] = np.array(shape)
+        out["near%d_center" % n] = np.array(c if c is not None else (-1, -1))
+        out["near%d_mg" % n] = np.array(mg)
+    save("geometry", **out)
+
+
 def gen_thresh_translate(sc):
     """update.threshold / measurement.threshold (log-histogram noise cut) and update.translation
     (Lanczos resampling by component.shift): SURVEY.md 8f rank 3, off the default pipeline."""
@@ -490,6 +510,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "extras3":
         gen_fit_extras3(sc)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "geometry":
+        gen_geometry(sc)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "extras":
         gen_fit_extras(sc)
         return
@@ -507,6 +530,7 @@ def main():
     gen_thresh_translate(sc)
     gen_fit_extras2(sc)
     gen_fit_extras3(sc)
+    gen_geometry(sc)
 
 
 if __name__ == "__main__":

@@ -213,3 +213,71 @@ def sort_by_radius(shape, center=None):
         cy, cx = int(center[0]), int(center[1])
     yy, xx = np.mgrid[:shape[0], :shape[1]]
     return np.argsort(np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2).flatten())
+
+
+def diagonalizeArray(arr, shape=None, dtype=np.float64):
+    """The 8 x N table of each pixel's eight neighbour values (row i = neighbour i in getOffsets'
+    order) and the mask of entries that do not exist, i.e. neighbours beyond the array
+    (reference operator.py:481-522).  Host-side set-up helper: the device kernels never need it.
+    The mask is the geometric one (a neighbour outside the array), which is what the reference's
+    slice and index arithmetic marks."""
+    if shape is None:
+        height, width = arr.shape
+        data = np.asarray(arr).reshape(-1)
+    elif np.ndim(arr) == 1:
+        height, width = shape
+        data = np.asarray(arr)
+    else:
+        raise ValueError("Expected either a 2D array or a 1D array and a shape")
+    plane = data.reshape(height, width)
+    yy, xx = np.mgrid[:height, :width]
+    diagonals = np.zeros((8, height * width), dtype=dtype)
+    mask = np.ones((8, height * width), dtype=bool)
+    for n, (oy, ox) in enumerate([(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]):
+        ok = (yy + oy >= 0) & (yy + oy < height) & (xx + ox >= 0) & (xx + ox < width)
+        src = plane[np.clip(yy + oy, 0, height - 1), np.clip(xx + ox, 0, width - 1)]
+        diagonals[n] = np.where(ok, src, 0).reshape(-1)
+        mask[n] = ~ok.reshape(-1)
+    return diagonals, mask
+
+
+def getRadialMonotonicWeights(shape, useNearest=True, minGradient=1, center=None):
+    """8 x N float64 table of the radial monotonicity operator (reference operator.py:540-621): for
+    every pixel the weights of its eight neighbours -- zero unless the neighbour exists and is
+    strictly closer to the peak; `useNearest`: `minGradient` on the single neighbour best aligned
+    with the direction to the peak; else cos(angle to that direction), normalised to sum one.
+    Memoised per (shape, centre, useNearest, minGradient) like the reference.  The HIP sweeps
+    generate these weights on the fly; this table exists for callers of the
+    reference API and for the host drop-ins of operators_pybind11."""
+    from .cache import Cache
+    if center is None:
+        center = ((shape[0] - 1) // 2, (shape[1] - 1) // 2)
+    name = "RadialMonotonicWeights"
+    key = tuple(shape) + tuple(center) + (useNearest, minGradient)
+    try:
+        return Cache.check(name, key)
+    except KeyError:
+        pass
+    H, W = int(shape[0]), int(shape[1])
+    py, px = int(center[0]), int(center[1])
+    yy, xx = np.mgrid[:H, :W]
+    Y = (yy - py).astype(np.float64)
+    X = (xx - px).astype(np.float64)
+    r2 = X * X + Y * Y
+    cosw = np.zeros((8, H * W), dtype=np.float64)
+    for n, (oy, ox) in enumerate([(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]):
+        exists = (yy + oy >= 0) & (yy + oy < H) & (xx + ox >= 0) & (xx + ox < W)
+        closer = (X + ox) ** 2 + (Y + oy) ** 2 < r2
+        with np.errstate(invalid="ignore", divide="ignore"):
+            c = (-X * ox - Y * oy) / (np.sqrt(r2) * np.sqrt(float(ox * ox + oy * oy)))
+        cosw[n] = np.where(exists & closer, c, 0.0).reshape(-1)
+    if useNearest:
+        out = np.zeros_like(cosw)
+        out[np.argmax(cosw, axis=0), np.arange(H * W)] = minGradient
+        out[:, px + py * W] = 0
+    else:
+        norm = cosw.sum(axis=0)
+        norm[norm == 0] = 1
+        out = cosw / norm[None, :]
+    Cache.set(name, key, out)
+    return out

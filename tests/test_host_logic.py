@@ -177,3 +177,33 @@ def test_interpolation_kernels_reference_vectors():
     truth_row2 = [0.028138304, -0.142694735, 0.696941621, 0.489860766, -0.115257837, 0.018469518]
     assert_almost_equal(k2[2], truth_row2)
     assert_array_equal(yw, [-2, -1, 0, 1, 2, 3]); assert_array_equal(xw, [-2, -1, 0, 1, 2, 3])
+
+
+def test_operator_geometry_helpers_match_the_reference():
+    """operator.getRadialMonotonicWeights (weighted tables of tests/golden/monotonic.npz, nearest tables of
+    geometry.npz) and operator.diagonalizeArray against outputs of the reference (oracle/gen_golden.py
+    gen_monotonic / gen_geometry): host-side set-up helpers of SURVEY.md 8a row a10."""
+    import scarlet_amd.operator as op
+    from scarlet_amd.cache import Cache
+    from conftest import load_golden
+    g = load_golden("monotonic")
+    for n in range(4):
+        Cache._cache = {}
+        w = op.getRadialMonotonicWeights(tuple(g["shape%d" % n]), useNearest=False, center=tuple(g["center%d" % n]))
+        assert np.abs(w - g["w%d" % n]).max() < 1e-15
+        assert op.getRadialMonotonicWeights(tuple(g["shape%d" % n]), useNearest=False,
+                                            center=tuple(g["center%d" % n])) is w       # memoised like the reference
+    g = load_golden("geometry")
+    for n in range(3):
+        Cache._cache = {}
+        c = tuple(g["near%d_center" % n])
+        w = op.getRadialMonotonicWeights(tuple(g["near%d_shape" % n]), useNearest=True,
+                                         minGradient=float(g["near%d_mg" % n]), center=None if c[0] < 0 else c)
+        assert_array_equal(w, g["near%d" % n])
+    d, m = op.diagonalizeArray(g["diag_in"])
+    assert_array_equal(m, g["diag_mask"])
+    assert_array_equal(d[~m], g["diag"][~m])
+    d2, _ = op.diagonalizeArray(g["diag_in"].reshape(-1), shape=(4, 5))
+    assert_array_equal(d2[~m], g["diag_flat"][~m])
+    with pytest.raises(ValueError):
+        op.diagonalizeArray(np.zeros((2, 2, 2)), shape=(2, 4))
