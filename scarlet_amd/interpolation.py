@@ -9,6 +9,39 @@ from . import _lib
 from .operator import _OnDevice
 
 
+def get_projection_slices(image, shape, yx0=None):
+    """Slices that place `image` into an array of `shape` -- its first pixel at shape // 2 + yx0, centred
+    (yx0 = -(image.shape // 2)) when yx0 is None -- clipped at the borders: (slices into the
+    projection, slices into the image, (bottom, top, left, right)) (reference interpolation.py:6-54).
+    Integer logic on the host."""
+    Ny, Nx = shape
+    iNy, iNx = image.shape
+    if yx0 is None:
+        yx0 = (-(iNy // 2), -(iNx // 2))
+    bottom = yx0[0] + (Ny >> 1)
+    left = yx0[1] + (Nx >> 1)
+    top, right = bottom + iNy, left + iNx
+    yslice = slice(max(0, bottom), min(Ny, top))
+    iyslice = slice(max(0, -bottom), max(Ny - bottom, -top))
+    xslice = slice(max(0, left), min(Nx, right))
+    ixslice = slice(max(0, -left), max(Nx - left, -right))
+    return (yslice, xslice), (iyslice, ixslice), (bottom, top, left, right)
+
+
+def project_image(image, shape, yx0=None):
+    """`image` padded with zeros and / or trimmed to `shape` (reference interpolation.py:57-84)."""
+    result = np.zeros(shape)
+    bb, ibb, _ = get_projection_slices(image, shape, yx0)
+    result[bb] = image[ibb]
+    return result
+
+
+def common_projections(img1, img2):
+    """Both images projected onto the smallest shape that holds them (reference interpolation.py:87-111)."""
+    shape = (max(img1.shape[0], img2.shape[0]), max(img1.shape[1], img2.shape[1]))
+    return project_image(img1, shape), project_image(img2, shape)
+
+
 def bilinear(dx):
     """Two-tap linear kernel for a shift by dx in [-1, 1] (reference interpolation.py:139-165)."""
     if np.abs(dx) > 1:

@@ -207,3 +207,50 @@ def test_operator_geometry_helpers_match_the_reference():
     assert_array_equal(d2[~m], g["diag_flat"][~m])
     with pytest.raises(ValueError):
         op.diagonalizeArray(np.zeros((2, 2, 2)), shape=(2, 4))
+
+
+def test_project_image_reference_vectors():
+    """interpolation.project_image / get_projection_slices: the known answers of the reference's
+    tests/test_interpolation.py:16-198 (odd -> odd, even -> even, odd -> even, even -> odd; centred and
+    with explicit corners, padding and trimming)."""
+    from scarlet_amd.interpolation import project_image, common_projections
+    odd, even = np.arange(35).reshape(5, 7), np.arange(48).reshape(8, 6)
+
+    def z(shape, dst, src):
+        t = np.zeros(shape); t[dst] = src
+        return t
+    S = slice
+    cases = [
+        # odd -> odd
+        (odd, (11, 9), None, z((11, 9), (S(3, -3), S(1, -1)), odd)),
+        (odd, (3, 3), None, odd[1:-1, 2:-2]),
+        (odd, (11, 9), (-6, -6), z((11, 9), (S(None, 4), S(None, 5)), odd[-4:, -5:])),
+        (odd, (3, 3), (-4, -6), z((3, 3), (S(None, 2), S(None, 2)), odd[-2:, -2:])),
+        (odd, (11, 9), (4, 0), z((11, 9), (S(-2, None), S(-5, None)), odd[:2, :5])),
+        (odd, (3, 3), (0, 1), z((3, 3), (S(-2, None), S(-1, None)), odd[:2, :1])),
+        # even -> even
+        (even, (12, 8), None, z((12, 8), (S(2, -2), S(1, -1)), even)),
+        (even, (6, 4), None, even[1:-1, 1:-1]),
+        (even, (14, 18), (-10, -11), z((14, 18), (S(None, 5), S(None, 4)), even[-5:, -4:])),
+        (even, (4, 4), (-1, -1), z((4, 4), (S(-3, None), S(-3, None)), even[:3, :3])),
+        (even, (12, 10), (3, 1), z((12, 10), (S(-3, None), S(-4, None)), even[:3, :4])),
+        (even, (4, 4), (0, -1), z((4, 4), (S(-2, None), S(-3, None)), even[:2, :3])),
+        # odd -> even
+        (odd, (10, 8), None, z((10, 8), (S(3, 8), S(1, None)), odd)),
+        (odd, (4, 4), None, odd[:4, 1:-2]),
+        (odd, (14, 18), (-9, -11), z((14, 18), (S(None, 3), S(None, 5)), odd[-3:, -5:])),
+        (odd, (4, 4), (-4, -5), z((4, 4), (S(None, 3), S(None, 4)), odd[-3:, -4:])),
+        (odd, (12, 10), (3, 1), z((12, 10), (S(-3, None), S(-4, None)), odd[:3, :4])),
+        (odd, (4, 4), (1, 0), z((4, 4), (S(-1, None), S(-2, None)), odd[:1, :2])),
+        # even -> odd
+        (even, (11, 9), None, z((11, 9), (S(1, -2), S(1, -2)), even)),
+        (even, (3, 3), None, even[3:-2, 2:-1]),
+        (even, (11, 9), (-9, -5), z((11, 9), (S(None, 4), S(None, 5)), even[-4:, -5:])),
+        (even, (3, 3), (-7, -5), z((3, 3), (S(None, 2), S(None, 2)), even[-2:, -2:])),
+        (even, (11, 9), (4, 0), z((11, 9), (S(-2, None), S(-5, None)), even[:2, :5])),
+        (even, (3, 3), (0, 1), z((3, 3), (S(-2, None), S(-1, None)), even[:2, :1])),
+    ]
+    for img, shape, yx0, truth in cases:
+        assert_array_equal(project_image(img, shape, yx0), truth)
+    a, b = common_projections(np.ones((3, 7)), np.ones((5, 4)))
+    assert a.shape == b.shape == (5, 7) and a.sum() == 21 and b.sum() == 20
