@@ -70,12 +70,28 @@ __device__ inline void wave_centroid(const Tile &t, const double *__restrict__ p
     const int rad = P / 2;
     const int ry = min(min(cy, t.H - 1 - cy), rad), rx = min(min(cx, t.W - 1 - cx), rad);
     const int hh = 2 * ry + 1, ww = 2 * rx + 1;
+    // one lane per window column (ww <= P <= 64 lanes), rows in the loop: no index division, the x moment of
+    // a lane is its column index times its column sum, four rows in flight (the weights come from L2)
     double s0 = 0, sy = 0, sx = 0;
-    for (int i = lane_id(); i < hh * ww; i += SC_WAVE) {
-        const int iy = i / ww, ix = i - iy * ww;
-        const double w = (double)t.m[(cy - ry + iy) * t.LW + (cx - rx + ix)] *
-                         psf[(rad - ry + iy) * P + (rad - rx + ix)];
-        s0 += w; sy += iy * w; sx += ix * w;
+    if (ww <= SC_WAVE) {
+        const int ix = lane_id();
+        if (ix < ww) {
+            const float *mp = t.m + (cy - ry) * t.LW + (cx - rx + ix);
+            const double *pp = psf + (rad - ry) * P + (rad - rx + ix);
+#pragma unroll 4
+            for (int iy = 0; iy < hh; ++iy) {
+                const double w = (double)mp[iy * t.LW] * pp[iy * P];
+                s0 += w; sy += (double)iy * w;
+            }
+            sx = (double)ix * s0;
+        }
+    } else {
+        for (int i = lane_id(); i < hh * ww; i += SC_WAVE) {
+            const int iy = i / ww, ix = i - iy * ww;
+            const double w = (double)t.m[(cy - ry + iy) * t.LW + (cx - rx + ix)] *
+                             psf[(rad - ry + iy) * P + (rad - rx + ix)];
+            s0 += w; sy += iy * w; sx += ix * w;
+        }
     }
     s0 = wave_sum(s0); sy = wave_sum(sy); sx = wave_sum(sx);
     const double my = sy / s0, mx = sx / s0;
