@@ -105,6 +105,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     __shared__ int lstop_s[KM];
     __shared__ float nmax_s[KM][2];
     __shared__ int pair_flag[KM][2];           // phase counters of the pair-local synchronisation
+    __shared__ double cent_s[KM][2][3];        // centroid moments of the two row halves
     __shared__ unsigned short fl_s[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wid = uniform(tid >> 6);    // wid in an SGPR: scalar branches
     float *const morph0 = a.morph[0], *const morph1 = a.morph[1], *const sed0 = a.sed[0], *const sed1 = a.sed[1];
@@ -398,8 +399,15 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         if (symmetric) {
             double dy = X ? pre_dy : a.shifts[2 * c], dx = X ? pre_dx : a.shifts[2 * c + 1];
             if (it_new % 5 == 0) {
-                // (the partner recomputes the same values: whatever it read from a.shifts is overwritten)
-                wave_centroid(t, a.centroid_psf, a.centroid_P, cy, cx, dy, dx, stat);
+                // the window rows are split between the two waves (even / odd): half as many round trips to the
+                // weight table in L2 on each wave's chain; both then add the two partial sums in the same
+                // order and finish identically
+                double p0, p1, p2;
+                wave_centroid_sums(t, a.centroid_psf, a.centroid_P, cy, cx, half, 2, p0, p1, p2);
+                if (lane == 0) { cent_s[k][half][0] = p0; cent_s[k][half][1] = p1; cent_s[k][half][2] = p2; }
+                pair_sync(1, std::false_type{});                    // B0 (centroid iterations only)
+                wave_centroid_finish(t, a.centroid_P, cent_s[k][0][0] + cent_s[k][1][0], cent_s[k][0][1] + cent_s[k][1][1],
+                                     cent_s[k][0][2] + cent_s[k][1][2], cy, cx, dy, dx, stat);
                 if (lead && lane == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
             }
             cy = uniform(cy); cx = uniform(cx); dy = uniform(dy); dx = uniform(dx);
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         }
     }
     STAMP(8);
-    if (mine) pair_sync(1, std::false_type{});                         // B1: Hankel vectors complete
+    if (mine) pair_sync(2, std::false_type{});                         // B1: Hankel vectors complete
     STAMP(12);
     f32x4 T[4][2];
     if (mine && mode == 1) {
@@ -442,11 +450,11 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         pair_ks_gemm1<true>(t, sw, kg, vec, half, T);
         STAMP(15);
     }
-    if (mine) pair_sync(2, std::false_type{});                         // B2: every read of X is done
+    if (mine) pair_sync(3, std::false_type{});                         // B2: every read of X is done
     STAMP(13);
     if (mine && mode == 1) pair_ks_gemm2<true>(t, sw, kg, vec, zv, half, T, sy, rank1);
     if (mine && mode == 2 && lead) wave_flip_symmetry<float>(t, sw, false, 1.0f);
-    if (mine) pair_sync(3, std::false_type{});                         // B3
+    if (mine) pair_sync(4, std::false_type{});                         // B3
     STAMP(9);
     // lane -> (row, float4 group) walk of the final pass without divisions: +128 groups per step
     const int dyq = (2 * SC_WAVE) / gpr, dxq = 2 * SC_WAVE - dyq * gpr;
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
         if (lane == 0) { lstop_s[k] = lstop; a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
         load_last();
     }
-    if (mine) pair_sync(4, std::true_type{});                         // B4: sweep done, lstop published
+    if (mine) pair_sync(5, std::true_type{});                         // B4: sweep done, lstop published
     STAMP(10);
     // ---- sparsity, positivity (update.py:71-82, 27-32), normalisation (update.py:62-65),
     // store, convergence sums: one pass over the LDS tile, float4 groups split between the pair
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
             if (__any(anynan)) vmax = __builtin_nanf("");
             if (lane == 0) nmax_s[k][half] = vmax;
         }
-        if (mine) pair_sync(5, std::false_type{});
+        if (mine) pair_sync(6, std::false_type{});
         if (mine) {
             const float m0 = nmax_s[k][0], m1 = nmax_s[k][1];
             norm = (m0 != m0 || m1 != m1) ? __builtin_nanf("") : fmaxf(m0, m1);

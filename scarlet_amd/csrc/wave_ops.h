@@ -64,22 +64,23 @@ __device__ inline void wave_max_pixel(const Tile &t, int &cy, int &cx, int &stat
 }
 
 // ---------------------------------------------------------------- a9 centroid
-__device__ inline void wave_centroid(const Tile &t, const double *__restrict__ psf, int P,
-                                     int &cy, int &cx, double &dy, double &dx, int &status_bits)
+// PSF-weighted moments of the window rows row0, row0 + rstep, ... (all rows: 0, 1): every lane gets the
+// wave's sums.  One lane per window column (ww <= P <= 64 lanes), rows in the loop: no index division, the
+// x moment of a lane is its column index times its column sum, four rows in flight (the weights come from L2)
+__device__ inline void wave_centroid_sums(const Tile &t, const double *__restrict__ psf, int P, int cy, int cx,
+                                          int row0, int rstep, double &s0, double &sy, double &sx)
 {
     const int rad = P / 2;
     const int ry = min(min(cy, t.H - 1 - cy), rad), rx = min(min(cx, t.W - 1 - cx), rad);
     const int hh = 2 * ry + 1, ww = 2 * rx + 1;
-    // one lane per window column (ww <= P <= 64 lanes), rows in the loop: no index division, the x moment of
-    // a lane is its column index times its column sum, four rows in flight (the weights come from L2)
-    double s0 = 0, sy = 0, sx = 0;
+    s0 = 0; sy = 0; sx = 0;
     if (ww <= SC_WAVE) {
         const int ix = lane_id();
         if (ix < ww) {
             const float *mp = t.m + (cy - ry) * t.LW + (cx - rx + ix);
             const double *pp = psf + (rad - ry) * P + (rad - rx + ix);
 #pragma unroll 4
-            for (int iy = 0; iy < hh; ++iy) {
+            for (int iy = row0; iy < hh; iy += rstep) {
                 const double w = (double)mp[iy * t.LW] * pp[iy * P];
                 s0 += w; sy += (double)iy * w;
             }
@@ -88,12 +89,20 @@ __device__ inline void wave_centroid(const Tile &t, const double *__restrict__ p
     } else {
         for (int i = lane_id(); i < hh * ww; i += SC_WAVE) {
             const int iy = i / ww, ix = i - iy * ww;
+            if (iy < row0 || (iy - row0) % rstep) continue;
             const double w = (double)t.m[(cy - ry + iy) * t.LW + (cx - rx + ix)] *
                              psf[(rad - ry + iy) * P + (rad - rx + ix)];
             s0 += w; sy += iy * w; sx += ix * w;
         }
     }
     s0 = wave_sum(s0); sy = wave_sum(sy); sx = wave_sum(sx);
+}
+// first moments -> new integer centre and sub-pixel shift (measurement.py:80-94)
+__device__ inline void wave_centroid_finish(const Tile &t, int P, double s0, double sy, double sx,
+                                            int &cy, int &cx, double &dy, double &dx, int &status_bits)
+{
+    const int rad = P / 2;
+    const int ry = min(min(cy, t.H - 1 - cy), rad), rx = min(min(cx, t.W - 1 - cx), rad);
     const double my = sy / s0, mx = sx / s0;
     if (!(my == my) || !(mx == mx) || isinf(my) || isinf(mx)) {
         status_bits |= SCARLET_STATUS_NONFINITE; dy = 0; dx = 0;
@@ -102,6 +111,13 @@ __device__ inline void wave_centroid(const Tile &t, const double *__restrict__ p
     const double wy = rint(my), wx = rint(mx);
     const int ncy = (int)wy + (cy - ry), ncx = (int)wx + (cx - rx);
     dy = wy - my; dx = wx - mx; cy = ncy; cx = ncx;
+}
+__device__ inline void wave_centroid(const Tile &t, const double *__restrict__ psf, int P,
+                                     int &cy, int &cx, double &dy, double &dx, int &status_bits)
+{
+    double s0, sy, sx;
+    wave_centroid_sums(t, psf, P, cy, cx, 0, 1, s0, sy, sx);
+    wave_centroid_finish(t, P, s0, sy, sx, cy, cx, dy, dx, status_bits);
 }
 
 // ---------------------------------------------------------------- a10/a11 sweep
