@@ -11,7 +11,7 @@ kw = {}
 if len(sys.argv) > 1 and sys.argv[1] == "nocons": kw = dict(symmetric=False, monotonic=False)
 b = BlendBatch(imgs, cen, **kw)
 b.init_extended(np.ones(5) * .1)
-b.fit(3, e_rel=0, check_every=0)
+b.fit(int(os.environ.get("STAMP_PRE", "3")), e_rel=0, check_every=0)
 torch.cuda.synchronize()
 b.workspace[:S * 16 * 8].zero_()
 b.fit(1, e_rel=0, check_every=0)
