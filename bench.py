@@ -1,23 +1,35 @@
 #!/usr/bin/env python
-"""Headline benchmark: proximal-gradient iterations/s on synthetic 5-band 64x64 scenes.
+"""Benchmark of the Blend.fit() hot path: proximal-gradient iterations/s on synthetic scenes.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5] [--strong]
 
-A "step" is one PGM iteration (Blend.fit inner loop: loss gradient, Lipschitz step,
-constraint pipeline, convergence flags) over the whole resident batch of scenes.
-Workload at N=1: BASELINE.json's metric configuration -- 10 000 scenes of 5 bands x
-64 x 64 pixels with 4 sources each, no PSF (configs[3] on one GPU; configs[1] is the
-same scene shape at batch 1024).  For N>1 every rank owns its own 10 000 scenes
-(weak scaling; scenes are independent, no collective in the timed region) and the
-fitted SEDs are gathered to rank 0 over RCCL afterwards.
+A "step" is one PGM iteration (Blend.fit inner loop: render [+ PSF convolution], loss gradient,
+Lipschitz step, constraint pipeline, convergence flags) over the whole resident batch of scenes.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
-objects: "roofline" (dominant kernel, HIP-event timed on the launch stream) and
-"cpu_baseline" (the CPU oracle timed on this host's cores, rank 0 at N=1 only).
+Workloads (`--config`, BASELINE.json `configs`):
+  c2 (default) 10 000 scenes per GPU of 5 bands x 64 x 64, 4 sources, no PSF -- the configuration
+               BASELINE.json's metric is quoted on (configs[3] on one GPU; configs[1] is the same
+               scene shape at batch 1024).
+  c3           4096 scenes per GPU of 5 x 128 x 128, 8 sources, per-band 41 x 41 PSF (FFT-convolution
+               path, configs[2]).
+  c5           64 scenes per GPU (= 512 over 8 GPUs) of 6 x 256 x 256, 30 overlapping sources,
+               symmetry + monotonicity + L0 (configs[4]).
+Multi-GPU: one process per GPU.  Run under torchrun (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the
+environment), or plainly as `python bench.py --gpus N`: with WORLD_SIZE unset and N > 1 this
+process starts the N rank processes itself (before it touches the GPU) and relays rank 0's line.
+Default = weak scaling: every rank owns its own `scenes` scenes, no collective in the timed
+region.  `--strong` = BASELINE configs[3] literally: rank 0 generates `scenes` scenes in total,
+scatters them over RCCL (timed separately), every rank fits its shard, results are gathered.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+"roofline" (dominant kernel class, HIP-event timed on the launch stream) and "cpu_baseline" (the
+CPU oracle timed on this host's cores -- one core and all cores -- rank 0 at N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +40,45 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_NAMES = ("k_grad", "k_step", "k_source_update", "k_converge", "k_iterate", "-", "-", "-")
+CLASS_NAMES = ("k_grad", "k_step", "k_source_update", "k_converge", "k_iterate", "psf_chain", "-", "-")
+
+CONFIGS = {
+    # scenes per GPU, bands, size, sources, psf, l0, min_sep, first scene index, distinct scenes generated
+    "c2": dict(S=10000, B=5, H=64, W=64, K=4, psf=False, l0=None, min_sep=4, first=0, unique=None,
+               cpu_scenes=24, cpu_iters=50,
+               label="%d scenes/GPU of 5-band 64x64, 4 sources/scene, no PSF (BASELINE configs[3] shape; "
+                     "configs[1] is the same at batch 1024)"),
+    "c3": dict(S=4096, B=5, H=128, W=128, K=8, psf=True, l0=None, min_sep=4, first=300, unique=64,
+               cpu_scenes=1, cpu_iters=10,
+               label="%d scenes/GPU of 5-band 128x128, 8 sources/scene, per-band 41x41 PSF, FFT-convolution "
+                     "render (BASELINE configs[2])"),
+    "c5": dict(S=64, B=6, H=256, W=256, K=30, psf=False, l0=0.05, min_sep=3, first=5000, unique=8,
+               cpu_scenes=1, cpu_iters=2,
+               label="%d scenes/GPU of 6-band 256x256, 30 overlapping sources/scene, symmetry + monotonicity + "
+                     "L0 (BASELINE configs[4]: 512 scenes over 8 GPUs)"),
+}
 
 
 def algorithmic_bytes_per_scene_iteration(B, K, H, W):
     """images read once, K morphs and SEDs read+written once."""
     return 4 * H * W * (B + 2 * K) + 8 * K * B
+
+
+def shard_range(n_scenes, rank, world):
+    """scarlet_amd.distributed.shard_range (not imported here: the package loads the HIP library, and
+    this process forks its host workers first)"""
+    base, rem = divmod(int(n_scenes), int(world))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def psf_setup(B):
+    """SURVEY.md 8d PSF configs: observed PSF_b = integrated Gaussian sigma 1.2 + 0.15 b on 41 x 41,
+    model PSF sigma 0.9; returns (obs_psfs, model_psf).  Runs in a worker process."""
+    from scarlet_amd import synth
+    obs = np.array([synth.gaussian_psf((41, 41), 1.2 + 0.15 * b) for b in range(B)])
+    model = synth.gaussian_psf((41, 41), 0.9)
+    return obs, model
 
 
 # ----------------------------------------------------------------------------- host workers
@@ -55,11 +100,23 @@ def _cpu_worker(args):
     """CPU oracle on a few scenes: returns (scene_iterations, seconds spent in fit)."""
     from oracle import pgm
     from scarlet_amd import synth
-    start, count, iters, kw = args
+    start, count, iters, kw, psf, l0 = args
+    diff = obs = model = None
+    if psf:
+        obs, model = psf_setup(kw["B"])
+        diff = pgm.match_psfs(obs, model[None])
     total, spent = 0, 0.0
     for i in range(count):
-        scn = synth.make_scene(start + i, **kw)
-        sc = pgm.make_extended_scene(scn["images"], scn["centers"], np.ones(kw["B"]) * 0.1)
+        scn = synth.make_scene(start + i, psfs=obs, **kw)
+        extra = {}
+        if psf:
+            extra = dict(obs_psfs=obs, frame_psf=model[None])
+        sc = pgm.make_extended_scene(scn["images"], scn["centers"], np.ones(kw["B"]) * 0.1, **extra)
+        if psf:
+            sc.diff_kernel = diff.astype(np.float32)
+        if l0 is not None:
+            for s in sc.sources:
+                s.l0_thresh = l0
         t0 = time.perf_counter()
         pgm.fit(sc, iters, e_rel=0)
         spent += time.perf_counter() - t0
@@ -67,19 +124,51 @@ def _cpu_worker(args):
     return total, spent
 
 
-def cpu_baseline(pool, workers, scenes_per_worker, iters, kw):
+def cpu_baseline(pool, workers, scenes_per_worker, iters, kw, psf, l0, first):
+    """The CPU oracle (numpy + C sweep, one scene at a time exactly like the reference) on a bounded
+    sample of the same workload: once on ONE core, once with one process per core."""
     from oracle import build as obuild
     obuild.build()
-    jobs = [(700000 + w * scenes_per_worker, scenes_per_worker, iters, kw) for w in range(workers)]
     t0 = time.perf_counter()
+    # one worker busy, the others idle (this process itself must not load the HIP library before its workers exit)
+    n1, s1 = pool.apply(_cpu_worker, ((first + 700000, scenes_per_worker, iters, kw, psf, l0),))
+    jobs = [(first + 700100 + w * scenes_per_worker, scenes_per_worker, iters, kw, psf, l0) for w in range(workers)]
     res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
     n = sum(r[0] for r in res)
-    # aggregate rate over the cores actually used (wall clock includes scene init)
-    busy = max(r[1] for r in res)
+    busy = max(r[1] for r in res)      # aggregate rate over the cores actually used
     return dict(value=n / busy, unit="scene-iterations/s", cores=workers, kind="port",
-                sample="%d scenes x %d iterations of the same workload, CPU oracle (numpy + C sweep), "
-                       "%d processes, fit() time only (wall %.1f s)" % (workers * scenes_per_worker, iters, workers, wall))
+                one_core=dict(value=n1 / s1, unit="scene-iterations/s", cores=1),
+                os_cpu_count=os.cpu_count(),
+                sample="%d scenes x %d iterations of the same workload per process, CPU oracle (numpy + C sweep), "
+                       "%d processes (all-core figure) and 1 process (one_core), fit() time only (wall %.1f s)"
+                       % (scenes_per_worker, iters, workers, wall))
+
+
+# ----------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (this process has not
+    touched the GPU and never will), wait for them, relay rank 0's output."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 # ----------------------------------------------------------------------------- main
@@ -88,38 +177,63 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scenes", type=int, default=10000, help="scenes per GPU")
-    ap.add_argument("--bands", type=int, default=5)
-    ap.add_argument("--size", type=int, default=64)
-    ap.add_argument("--sources", type=int, default=4)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--scenes", type=int, default=None, help="scenes per GPU (total scenes with --strong)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: `scenes` in total, generated on rank 0 and scattered over RCCL")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-scenes", type=int, default=24, help="oracle scenes per host process")
-    ap.add_argument("--cpu-iters", type=int, default=50)
+    ap.add_argument("--cpu-scenes", type=int, default=None, help="oracle scenes per host process")
+    ap.add_argument("--cpu-iters", type=int, default=None)
     ap.add_argument("--no-symmetric", action="store_true", help="ablation: drop the symmetry constraint")
     ap.add_argument("--no-monotonic", action="store_true", help="ablation: drop the monotonicity constraint")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world != args.gpus and world > 1:
-        print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
-    B, H, W, K, S = args.bands, args.size, args.size, args.sources, args.scenes
-    kw = dict(B=B, H=H, W=W, K=K)
+    if world != args.gpus:
+        print("error: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    cfg = CONFIGS[args.config]
+    B, H, W, K = cfg["B"], cfg["H"], cfg["W"], cfg["K"]
+    S_arg = args.scenes if args.scenes is not None else cfg["S"]
+    kw = dict(B=B, H=H, W=W, K=K, min_sep=cfg["min_sep"])
+    obs_psfs = model_psf = None
 
-    # ---- host-side work first, in forked workers, BEFORE this process touches the GPU
+    # ---- host-side work first, in forked workers, BEFORE this process loads the HIP library
     import multiprocessing as mp
     share = max(1, (os.cpu_count() or 1) // max(1, world))
     workers = max(1, min(16, share))
     pool = mp.get_context("fork").Pool(workers)
     cpu = None
+    images = centers = None
     try:
+        if cfg["psf"]:
+            obs_psfs, model_psf = pool.apply(psf_setup, (B,))
         if rank == 0 and world == 1 and not args.no_cpu:
-            cpu = cpu_baseline(pool, workers, args.cpu_scenes, args.cpu_iters, kw)
+            cpu = cpu_baseline(pool, workers, args.cpu_scenes or cfg["cpu_scenes"], args.cpu_iters or cfg["cpu_iters"],
+                               kw, cfg["psf"], cfg["l0"], cfg["first"])
         t0 = time.perf_counter()
-        images, centers = generate_scenes(rank * S, S, pool, workers, **kw)
+        if args.strong:
+            S_total = S_arg
+            lo, hi = shard_range(S_total, rank, world)
+            S = hi - lo
+            n_gen, start = (S_total, cfg["first"]) if rank == 0 else (0, 0)
+        else:
+            S, S_total = S_arg, S_arg * world
+            n_gen, start = S, cfg["first"] + rank * S
+        if n_gen:
+            uniq = min(n_gen, cfg["unique"] or n_gen)
+            gkw = dict(kw, psfs=obs_psfs) if cfg["psf"] else kw
+            images, centers = generate_scenes(start, uniq, pool, workers, **gkw)
+            if uniq < n_gen:                 # large frames: a few distinct scenes, tiled (scenes are independent)
+                reps = (n_gen + uniq - 1) // uniq
+                images = np.tile(images, (reps, 1, 1, 1))[:n_gen]
+                centers = np.tile(centers, (reps, 1, 1))[:n_gen]
         t_gen = time.perf_counter() - t0
     finally:
         pool.close()
@@ -134,11 +248,41 @@ def main():
     # the N > 1 control flow (the real N > 1 runs use one GPU per rank and RCCL)
     rehearse = bool(os.environ.get("SCARLET_BENCH_REHEARSE"))
     torch.cuda.set_device(local if world > 1 and not rehearse else 0)
-    distributed.init_from_env(("gloo" if rehearse else "nccl") if world > 1 else None)
+    backend = ("gloo" if rehearse else "nccl") if world > 1 else None
+    distributed.init_from_env(backend)
+    dev = torch.device("cuda", torch.cuda.current_device())
 
-    batch = BlendBatch(images, centers, mse_capacity=args.steps + args.warmup + 1,
-                       symmetric=not args.no_symmetric, monotonic=not args.no_monotonic)
-    batch.init_extended(np.ones(B, dtype=np.float32) * 0.1)
+    t_scatter = 0.0
+    if args.strong and world > 1:
+        # configs[3]: rank 0 holds all scenes; one scatter of images + centres over RCCL (xGMI)
+        if rank == 0:
+            tens = [torch.as_tensor(images).to(dev), torch.as_tensor(centers).to(dev)]
+            if rehearse:
+                tens = [t.cpu() for t in tens]
+        else:
+            tens = None
+        torch.cuda.synchronize()
+        distributed.barrier()
+        t0 = time.perf_counter()
+        images_t, centers_t = distributed.scatter_scenes(tens, S_total)
+        torch.cuda.synchronize()
+        distributed.barrier()
+        t_scatter = distributed.max_over_ranks(time.perf_counter() - t0)
+        images, centers = images_t.to(dev), centers_t.to(dev)
+
+    bkw = dict(mse_capacity=args.steps + args.warmup + 1, symmetric=not args.no_symmetric,
+               monotonic=not args.no_monotonic, l0_thresh=cfg["l0"])
+    if cfg["psf"]:
+        bkw["centroid_weight"] = model_psf.astype(np.float32)
+    batch = BlendBatch(images, centers, **bkw)
+    sed_scale = None
+    if cfg["psf"]:
+        from scarlet_amd import fft as fftmod
+        diff = fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                 fftmod.Fourier(model_psf[None].astype(np.float32))).image
+        batch.set_diff_kernel(np.asarray(diff, dtype=np.float32))
+        sed_scale = (model_psf.max() / obs_psfs.max(axis=(1, 2))).astype(np.float32)
+    batch.init_extended(np.ones(B, dtype=np.float32) * 0.1, sed_scale=sed_scale)
     torch.cuda.synchronize()
     if args.warmup > 0:
         batch.fit(args.warmup, e_rel=0, check_every=0)
@@ -160,28 +304,43 @@ def main():
     n_active = int(batch.active.sum().item())
     status_bad = int((batch.status != 0).sum().item())
 
-    # results travel back to rank 0 over RCCL (outside the timed region)
-    gathered = distributed.gather_scenes([batch.sed_current, batch.mse_buf[:, :args.steps + args.warmup]],
-                                         S * world)
+    # results travel back to rank 0 over RCCL (outside the fit-only timed region; timed on its own)
+    torch.cuda.synchronize()
+    distributed.barrier()
+    t0 = time.perf_counter()
+    payload = [batch.sed_current, batch.mse_buf[:, :args.steps + args.warmup]]
+    if args.strong:
+        payload.append(batch.morph_current)
+    gathered = distributed.gather_scenes(payload, S_total if args.strong else S * world)
+    torch.cuda.synchronize()
+    distributed.barrier()
+    t_gather = distributed.max_over_ranks(time.perf_counter() - t0)
     if rank != 0:
         return
-    total_scene_iters = float(S) * world * args.steps
+    total_scene_iters = float(S_total) * args.steps
     value = total_scene_iters / elapsed
     bytes_unit = algorithmic_bytes_per_scene_iteration(B, K, H, W)
+    S0 = S                                               # scenes per launch on rank 0
+    per_class = {CLASS_NAMES[i]: ms[i] / cnt[i] for i in range(8) if cnt[i]}
     dom = int(np.argmax([ms[i] for i in range(8)]))
-    avg_ms = ms[dom] / max(1, cnt[dom])
-    achieved = bytes_unit * S / (avg_ms * 1e-3) / 1e9
+    launches_per_iter = max(1, int(round(cnt[dom] / float(args.steps))))
+    avg_ms = ms[dom] / max(1, cnt[dom]) * launches_per_iter        # the class's time per iteration
+    achieved = bytes_unit * S0 / (avg_ms * 1e-3) / 1e9
     it_ms = 1e3 * elapsed / args.steps
     mse = gathered[1].cpu().numpy()
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
     # the figure is the one measured with rocprofv3 --pmc passes of this same command and committed
     # under profiles/ (per launch of the same kernel at the same scenes-per-launch), else null.
-    # the fused iteration has two variants (scarlet_hip.hip launch_fused); name the one that ran
-    kernel_label = KERNEL_NAMES[dom]
+    kernel_label = CLASS_NAMES[dom]
     if dom == 4:
+        # the fused iteration has two variants (scarlet_hip.hip launch_fused); name the one that ran
         kernel_label = "k_iterate2<4,5,0>" if (K <= 4 and B <= 5 and not os.environ.get("SCARLET_FUSED_V1")) else "k_iterate"
         if kernel_label.startswith("k_iterate2") and (K, B, H, W) == (4, 5, 64, 64) and not os.environ.get("SCARLET_NO_EXACT"):
             kernel_label = "k_iterate2<4,5,64>"        # the exact-shape instance (default pipeline, unit weights)
+    elif dom == 5:
+        kernel_label = "k_psf_conv (render + adjoint, LDS-resident FFT)" if not os.environ.get("SCARLET_PSF_HIPFFT") else "psf_chain (hipFFT)"
+    elif dom == 2:
+        kernel_label = "k_source_update"
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes" if args.traffic_bytes else None
     if traffic is None:
         import glob
@@ -190,11 +349,13 @@ def main():
                 pm = json.load(open(f))
             except Exception:
                 continue
-            if kernel_label.replace(",", ", ") in pm.get("kernel", "") and pm.get("scenes_per_launch") == S:
+            if kernel_label.split(" ")[0].replace(",", ", ") in pm.get("kernel", "") and pm.get("scenes_per_launch") == S0:
                 traffic, traffic_src = pm["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
                 break
+    metric = "PGM iters/sec on 10k 5-band 64x64 scenes" if args.config == "c2" else \
+        "PGM iters/sec (%s)" % args.config
     out = {
-        "metric": "PGM iters/sec on 10k 5-band 64x64 scenes",
+        "metric": metric,
         "value": value,
         "unit": "scene-iterations/s",
         "n_gpus": world,
@@ -202,28 +363,32 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": it_ms,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%d scenes/GPU of %d-band %dx%d, %d sources/scene, no PSF "
-                               "(BASELINE configs[3] shape; configs[1] is the same at batch 1024)" % (S, B, H, W, K),
-                   "scenes_per_gpu": S, "bands": B, "height": H, "width": W, "sources": K,
+        "config": {"workload": cfg["label"] % S0 + (" -- STRONG scaling: %d scenes in total" % S_total if args.strong else ""),
+                   "config": args.config, "scenes_per_gpu": S0, "scenes_total": S_total,
+                   "bands": B, "height": H, "width": W, "sources": K,
                    "parallelism": "scenes sharded, %d rank(s), no collective in the iteration" % world,
                    "batch_iterations_per_s": args.steps / elapsed,
                    "active_scenes_after_timed_region": n_active, "scenes_with_status": status_bad,
                    "mean_loss_first_last": [float(mse[:, 0].mean()), float(mse[:, -1].mean())],
-                   "host_scene_generation_s": t_gen},
+                   "host_scene_generation_s": t_gen,
+                   "scatter_s": t_scatter, "gather_s": t_gather,
+                   "end_to_end_scene_iterations_per_s": total_scene_iters / (elapsed + t_scatter + t_gather)},
         "roofline": {"bound": "hbm", "kernel": kernel_label, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": bytes_unit * S, "avg_launch_ms": avg_ms,
-                     "per_kernel_avg_ms": {KERNEL_NAMES[i]: ms[i] / cnt[i] for i in range(8) if cnt[i]},
-                     "whole_iteration_frac": bytes_unit * S / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "algorithmic_bytes_per_launch": bytes_unit * S0, "avg_launch_ms": avg_ms,
+                     "launches_per_iteration_in_class": launches_per_iter,
+                     "per_class_avg_ms": per_class,
+                     "whole_iteration_frac": bytes_unit * S0 / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
     if cpu is not None:
         out["cpu_baseline"] = cpu
         out["config"]["gpu_over_cpu_all_cores"] = value / cpu["value"]
+        out["config"]["gpu_over_cpu_one_core"] = value / cpu["one_core"]["value"]
     print(json.dumps(out))
 
 

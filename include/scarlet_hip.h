@@ -19,8 +19,16 @@
  * device arrays are C-contiguous float32 unless stated otherwise.  `stream` is a
  * hipStream_t passed as void*; every device entry point is asynchronous on it and
  * allocates nothing.  Return value: 0 = ok, negative = SCARLET_E_* (argument errors
- * are detected on the host before any launch).  No global state except the
- * constant table of fast FFT lengths initialised on first use.
+ * are detected on the host before any launch).
+ *
+ * Threads and global state.  Every entry point may be called from several host threads at once
+ * on different batches / streams; scarlet_last_error() is per thread.  The library keeps exactly
+ * four process-wide objects, each behind its own mutex or atomic: the constant table of fast
+ * FFT lengths (filled once per device), the hipFFT plan cache of the large-frame fallback of the
+ * PSF path, the diagnostic switches of scarlet_set_option(), and the event recorder of
+ * scarlet_profile_begin/end (one profiled region at a time, whichever batch launches inside it).
+ * Set-up and host-pointer entry points that need temporary device memory release it on every
+ * exit path, error paths included.
  */
 #ifndef SCARLET_HIP_H
 #define SCARLET_HIP_H
@@ -64,6 +72,12 @@ extern "C" {
 
 const char *scarlet_version(void);
 const char *scarlet_last_error(void);
+/* Diagnostic switches: NO_EXACT, NO_KSCACHE, FUSED_V1, NO_FUSED, FORCE_BLOCK_UPDATE,
+ * NO_HYBRID_SWEEP, PAD_LDS, STAMPS, PSF_HIPFFT, NO_PERSIST.  Each starts from the environment variable
+ * SCARLET_<NAME>, read once at first use; afterwards only this call changes it.  Returns the
+ * previous value (0 / 1) or SCARLET_E_ARG for an unknown name.  None changes results beyond
+ * float32 rounding. */
+int scarlet_set_option(const char *name, int value);
 /* 5-smooth fast FFT length (scipy.fftpack.next_fast_len as used by fft.py:99) */
 int scarlet_next_fast_len(int n);
 

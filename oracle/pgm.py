@@ -561,6 +561,9 @@ def source_update(src, it):
         prox_hard(src.morph, 1 / src.L_morph, src.l0_thresh)
     if src.l1_thresh is not None:
         prox_soft(src.morph, 1 / src.L_morph, src.l1_thresh)
+    if getattr(src, "trace", None) is not None:
+        # test hook (tests/test_gpu_parity_long.py): the morphology as prox_plus is about to see it
+        src.trace.append(src.morph.copy())
     prox_plus(src.sed)
     prox_plus(src.morph)
     normalize(src.sed, src.morph, "morph_max")
@@ -709,8 +712,9 @@ def check_convergence(scene, e_rel):
     return done
 
 
-def fit(scene, max_iter=200, e_rel=1e-2, approximate_L=False):
-    """Blend.fit (blend.py:65-102), one scene, single observation."""
+def fit(scene, max_iter=200, e_rel=1e-2, approximate_L=False, callback=None):
+    """Blend.fit (blend.py:65-102), one scene, single observation.  `callback(scene)` (test hook) runs
+    after every iteration's update, before the convergence check."""
     for _ in range(max_iter):
         seds = [c.sed for c in scene.sources]
         morphs = [c.morph for c in scene.sources]
@@ -762,6 +766,8 @@ def fit(scene, max_iter=200, e_rel=1e-2, approximate_L=False):
         else:
             for c in scene.sources:
                 source_update(c, it)
+        if callback is not None:
+            callback(scene)
         if check_convergence(scene, e_rel):
             break
     return scene

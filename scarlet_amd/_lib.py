@@ -57,6 +57,7 @@ _P = c_void_p
 _SIGNATURES = {
     "scarlet_version": (c_char_p, []),
     "scarlet_last_error": (c_char_p, []),
+    "scarlet_set_option": (c_int, [c_char_p, c_int]),
     "scarlet_next_fast_len": (c_int, [c_int]),
     "scarlet_host_prox_monotonic_f64": (c_int, [_P, c_int, _P, _P, c_int, c_double]),
     "scarlet_host_prox_weighted_monotonic_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_float]),
@@ -98,6 +99,11 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header/library mismatch
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+def set_option(name, value):
+    """Diagnostic switch of the library (scarlet_set_option); returns the previous value."""
+    return check(lib.scarlet_set_option(name.encode(), int(value)))
 
 
 def last_error():

@@ -6,7 +6,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <vector>
 #include <hipfft/hipfft.h>
@@ -38,7 +40,51 @@ static int set_err(int code, const char *msg)
         }                                                                                \
     } while (0)
 
-extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.1 (gfx950)"; }
+extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx950)"; }
+
+// ---- diagnostic switches: process-wide integers, initialised ONCE from the
+// environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
+// None of them changes results beyond float32 rounding.
+enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_COUNT };
+static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
+                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST"};
+static std::atomic<int> g_opt[OPT_COUNT];
+static std::once_flag g_opt_once;
+static void options_init(void)
+{
+    std::call_once(g_opt_once, [] {
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            char name[64];
+            snprintf(name, sizeof(name), "SCARLET_%s", g_opt_names[i]);
+            const char *v = getenv(name);
+            int val = 0;
+            if (v) { val = atoi(v); if (val == 0 && v[0] != '0') val = 1; }    // "yes", "" ... count as on
+            if (v && !v[0]) val = 1;
+            g_opt[i].store(val, std::memory_order_relaxed);
+        }
+    });
+}
+static inline int opt(int which) { options_init(); return g_opt[which].load(std::memory_order_relaxed); }
+extern "C" int scarlet_set_option(const char *name, int value)
+{
+    options_init();
+    if (!name) return set_err(SCARLET_E_ARG, "null option name");
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_names[i])) return g_opt[i].exchange(value) != 0 ? 1 : 0;
+    return set_err(SCARLET_E_ARG, "unknown option");
+}
+
+// device allocation released on every exit path of the set-up / host-pointer entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    template <typename T> T *as() const { return (T *)p; }
+};
+#define DEV_ALLOC(buf, bytes) HIP_TRY(hipMalloc(&(buf).p, (bytes)))
 extern "C" const char *scarlet_last_error(void) { return g_err; }
 
 // scipy.fftpack.next_fast_len: smallest 2^a 3^b 5^c >= n
@@ -58,6 +104,8 @@ extern "C" int scarlet_next_fast_len(int n)
 static int ensure_tables(void)
 {
     static bool done[64] = {false};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return set_err(SCARLET_E_HIP, "device index out of range");
@@ -205,7 +253,7 @@ static int launch_operator(OpArgs a, void *stream)
     if (a.n == 0) return SCARLET_OK;
     int rc = ensure_tables();
     if (rc) return rc;
-    if (a.H <= 64 && a.W <= 64 && a.op != OP_MONO_NEAREST && !getenv("SCARLET_FORCE_BLOCK_UPDATE")) {
+    if (a.H <= 64 && a.W <= 64 && a.op != OP_MONO_NEAREST && !opt(OPT_FORCE_BLOCK_UPDATE)) {
         const size_t lds = sizeof(float) * SC_NWAVES * ((size_t)a.H * tile_stride(a.W) + SC_WAVE_VEC_FLOATS);
         rc = allow_lds(k_operator_w, lds);
         if (rc) return rc;
@@ -218,15 +266,13 @@ static int launch_operator(OpArgs a, void *stream)
         hipLaunchKernelGGL(k_operator<false>, dim3(a.n), dim3(SC_BLOCK), lds, (hipStream_t)stream, a, (float *)nullptr);
     } else {
         if (a.H > 256) return set_err(SCARLET_E_TOO_LARGE, "arrays larger than 256 x 256 are not supported");
-        float *gscratch = nullptr;
+        DevBuf gscratch;                      // released on every path, after the kernel has finished
         if (a.op == OP_SYMMETRY)
-            HIP_TRY(hipMalloc(&gscratch, sizeof(float) * (size_t)a.n * round16(a.H) * scratch_stride(round16(a.W))));
+            DEV_ALLOC(gscratch, sizeof(float) * (size_t)a.n * round16(a.H) * scratch_stride(round16(a.W)));
         const size_t lds = sizeof(float) * (2 * round16(a.H) + 5 * round16(a.W) + stage_floats(round16(a.H), round16(a.W)));
-        hipLaunchKernelGGL(k_operator<true>, dim3(a.n), dim3(SC_BLOCK), lds, (hipStream_t)stream, a, gscratch);
-        const hipError_t e1 = hipGetLastError();
-        hipError_t e2 = hipSuccess;
-        if (gscratch) { e2 = hipStreamSynchronize((hipStream_t)stream); (void)hipFree(gscratch); }
-        HIP_TRY(e1); HIP_TRY(e2);
+        hipLaunchKernelGGL(k_operator<true>, dim3(a.n), dim3(SC_BLOCK), lds, (hipStream_t)stream, a, gscratch.as<float>());
+        HIP_TRY(hipGetLastError());
+        if (gscratch.p) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     }
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;
@@ -476,10 +522,10 @@ __global__ void k_host_nearest(double *x, const int *ref_idx, const int *dist_id
 }
 
 template <typename T>
-static int dev_alloc_copy(T **dptr, const T *host, size_t count)
+static int dev_alloc_copy(DevBuf &buf, const T *host, size_t count)
 {
-    HIP_TRY(hipMalloc((void **)dptr, count * sizeof(T) + 16));
-    if (host) HIP_TRY(hipMemcpy(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+    DEV_ALLOC(buf, count * sizeof(T) + 16);
+    if (host) HIP_TRY(hipMemcpy(buf.p, host, count * sizeof(T), hipMemcpyHostToDevice));
     return SCARLET_OK;
 }
 
@@ -488,16 +534,18 @@ static int host_weighted(T *x, int n, const T *weights, const int *offsets, cons
                          int n_dist, T thresh)
 {
     if (!x || !weights || !offsets || !dist_idx || n <= 0 || n_dist < 0) return set_err(SCARLET_E_ARG, "bad arguments");
-    T *dx = nullptr, *dw = nullptr; int *doff = nullptr, *dd = nullptr;
+    for (int d = 0; d < n_dist; ++d)                       // the reference does not bounds-check (mutable_unchecked)
+        if (dist_idx[d] < 0 || dist_idx[d] >= n) return set_err(SCARLET_E_ARG, "dist_idx out of range");
+    DevBuf dx, dw, doff, dd;
     int rc;
-    if ((rc = dev_alloc_copy(&dx, x, n))) return rc;
-    if ((rc = dev_alloc_copy(&dw, weights, (size_t)8 * n))) return rc;
-    if ((rc = dev_alloc_copy(&doff, offsets, 8))) return rc;
-    if ((rc = dev_alloc_copy(&dd, dist_idx, n_dist > 0 ? n_dist : 1))) return rc;
-    hipLaunchKernelGGL(k_host_weighted<T>, dim3(1), dim3(SC_WAVE), 0, 0, dx, n, dw, doff, dd, n_dist, thresh);
+    if ((rc = dev_alloc_copy(dx, x, n))) return rc;
+    if ((rc = dev_alloc_copy(dw, weights, (size_t)8 * n))) return rc;
+    if ((rc = dev_alloc_copy(doff, offsets, 8))) return rc;
+    if ((rc = dev_alloc_copy(dd, dist_idx, n_dist > 0 ? n_dist : 1))) return rc;
+    hipLaunchKernelGGL(k_host_weighted<T>, dim3(1), dim3(SC_WAVE), 0, 0, dx.as<T>(), n, dw.as<T>(), doff.as<int>(),
+                       dd.as<int>(), n_dist, thresh);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(x, dx, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(doff); (void)hipFree(dd);
+    HIP_TRY(hipMemcpy(x, dx.p, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
     return SCARLET_OK;
 }
 
@@ -512,15 +560,17 @@ extern "C" int scarlet_host_prox_monotonic_f64(double *x, int n, const int *ref_
                                                int n_dist, double thresh)
 {
     if (!x || !ref_idx || !dist_idx || n <= 0 || n_dist < 0) return set_err(SCARLET_E_ARG, "bad arguments");
-    double *dx = nullptr; int *dr = nullptr, *dd = nullptr;
+    for (int d = 0; d < n_dist; ++d)
+        if (dist_idx[d] < 0 || dist_idx[d] >= n || ref_idx[dist_idx[d]] < 0 || ref_idx[dist_idx[d]] >= n)
+            return set_err(SCARLET_E_ARG, "dist_idx / ref_idx out of range");
+    DevBuf dx, dr, dd;
     int rc;
-    if ((rc = dev_alloc_copy(&dx, x, n))) return rc;
-    if ((rc = dev_alloc_copy(&dr, ref_idx, n))) return rc;
-    if ((rc = dev_alloc_copy(&dd, dist_idx, n_dist > 0 ? n_dist : 1))) return rc;
-    hipLaunchKernelGGL(k_host_nearest, dim3(1), dim3(SC_WAVE), 0, 0, dx, dr, dd, n_dist, thresh);
+    if ((rc = dev_alloc_copy(dx, x, n))) return rc;
+    if ((rc = dev_alloc_copy(dr, ref_idx, n))) return rc;
+    if ((rc = dev_alloc_copy(dd, dist_idx, n_dist > 0 ? n_dist : 1))) return rc;
+    hipLaunchKernelGGL(k_host_nearest, dim3(1), dim3(SC_WAVE), 0, 0, dx.as<double>(), dr.as<int>(), dd.as<int>(), n_dist, thresh);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(x, dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dr); (void)hipFree(dd);
+    HIP_TRY(hipMemcpy(x, dx.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return SCARLET_OK;
 }
 
@@ -529,18 +579,18 @@ extern "C" int scarlet_host_apply_filter_f32(const float *image, int H, int W, c
                                              const int *x_end, int n, float *result)
 {
     if (!image || !result || H <= 0 || W <= 0 || n < 0) return set_err(SCARLET_E_ARG, "bad arguments");
-    float *di = nullptr, *dv = nullptr, *dr = nullptr; int *idx[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (n > 0 && (!values || !y_start || !y_end || !x_start || !x_end)) return set_err(SCARLET_E_ARG, "bad arguments");
+    DevBuf di, dv, dr, idx[4];
     const int *hidx[4] = {y_start, y_end, x_start, x_end};
     int rc;
-    if ((rc = dev_alloc_copy(&di, image, (size_t)H * W))) return rc;
-    if ((rc = dev_alloc_copy(&dv, values, n > 0 ? n : 1))) return rc;
-    if ((rc = dev_alloc_copy(&dr, (const float *)nullptr, (size_t)H * W))) return rc;
-    for (int i = 0; i < 4; ++i) if ((rc = dev_alloc_copy(&idx[i], hidx[i], n > 0 ? n : 1))) return rc;
-    rc = scarlet_apply_filter(di, H, W, dv, idx[0], idx[1], idx[2], idx[3], n, dr, nullptr);
+    if ((rc = dev_alloc_copy(di, image, (size_t)H * W))) return rc;
+    if ((rc = dev_alloc_copy(dv, values, n > 0 ? n : 1))) return rc;
+    if ((rc = dev_alloc_copy(dr, (const float *)nullptr, (size_t)H * W))) return rc;
+    for (int i = 0; i < 4; ++i) if ((rc = dev_alloc_copy(idx[i], hidx[i], n > 0 ? n : 1))) return rc;
+    rc = scarlet_apply_filter(di.as<float>(), H, W, dv.as<float>(), idx[0].as<int>(), idx[1].as<int>(), idx[2].as<int>(),
+                              idx[3].as<int>(), n, dr.as<float>(), nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(result, dr, (size_t)H * W * sizeof(float), hipMemcpyDeviceToHost));
-    (void)hipFree(di); (void)hipFree(dv); (void)hipFree(dr);
-    for (int i = 0; i < 4; ++i) (void)hipFree(idx[i]);
+    HIP_TRY(hipMemcpy(result, dr.p, (size_t)H * W * sizeof(float), hipMemcpyDeviceToHost));
     return SCARLET_OK;
 }
 
@@ -550,14 +600,17 @@ extern "C" int scarlet_host_apply_filter_f32(const float *image, int H, int W, c
 // ---- optional per-kernel event timing (scarlet_profile_begin/end)
 #define SC_NCLASS 8
 struct Profiler {
-    bool on = false;
+    std::atomic<bool> on{false};
     std::vector<hipEvent_t> ev;     // pairs (start, stop)
     std::vector<int> cls;
     int used = 0, cap = 0;
 };
-static Profiler g_prof;
+static Profiler g_prof;                // process-wide: one profiled fit at a time (documented in the header)
+static std::mutex g_prof_mu;
 static inline void prof_start(int cls, hipStream_t st)
 {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (g_prof.on && g_prof.used < g_prof.cap) {
         g_prof.cls[g_prof.used] = cls;
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
@@ -565,6 +618,8 @@ static inline void prof_start(int cls, hipStream_t st)
 }
 static inline void prof_stop(hipStream_t st)
 {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (g_prof.on && g_prof.used < g_prof.cap) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], st);
         ++g_prof.used;
@@ -573,6 +628,7 @@ static inline void prof_stop(hipStream_t st)
 extern "C" int scarlet_profile_begin(int max_iterations)
 {
     if (max_iterations <= 0) return set_err(SCARLET_E_ARG, "max_iterations <= 0");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto e : g_prof.ev) (void)hipEventDestroy(e);
     const int cap = max_iterations * 4;
     g_prof.ev.assign((size_t)cap * 2, nullptr);
@@ -583,6 +639,7 @@ extern "C" int scarlet_profile_begin(int max_iterations)
 }
 extern "C" int scarlet_profile_end(double total_ms[SC_NCLASS], int64_t launches[SC_NCLASS])
 {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_prof.on) return set_err(SCARLET_E_ARG, "profiler not active");
     g_prof.on = false;
     for (int k = 0; k < SC_NCLASS; ++k) { total_ms[k] = 0; launches[k] = 0; }
@@ -727,8 +784,11 @@ static GradArgs grad_args(const scarlet_batch *b, int approximate_L, int raw_gra
 // ---- hipFFT plan cache: one (R2C, C2R) pair per (Fy, Fx, batch)
 struct FftPlans { hipfftHandle r2c, c2r; };
 static std::map<std::tuple<int, int, int>, FftPlans> g_plans;
+static std::mutex g_plans_mu;          // guards the map; a plan's stream is set and used under g_fft_exec_mu
+static std::mutex g_fft_exec_mu;
 static int get_plans(int Fy, int Fx, int batch, FftPlans *out)
 {
+    std::lock_guard<std::mutex> lock(g_plans_mu);
     auto key = std::make_tuple(Fy, Fx, batch);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
@@ -744,6 +804,7 @@ static int get_plans(int Fy, int Fx, int batch, FftPlans *out)
 }
 static int fft_r2c(const FftPlans &p, float *in, float2 *out, hipStream_t st)
 {
+    std::lock_guard<std::mutex> lock(g_fft_exec_mu);
     if (hipfftSetStream(p.r2c, st) != HIPFFT_SUCCESS ||
         hipfftExecR2C(p.r2c, (hipfftReal *)in, (hipfftComplex *)out) != HIPFFT_SUCCESS)
         return set_err(SCARLET_E_HIP, "hipfftExecR2C failed");
@@ -751,6 +812,7 @@ static int fft_r2c(const FftPlans &p, float *in, float2 *out, hipStream_t st)
 }
 static int fft_c2r(const FftPlans &p, float2 *in, float *out, hipStream_t st)
 {
+    std::lock_guard<std::mutex> lock(g_fft_exec_mu);
     if (hipfftSetStream(p.c2r, st) != HIPFFT_SUCCESS ||
         hipfftExecC2R(p.c2r, (hipfftComplex *)in, (hipfftReal *)out) != HIPFFT_SUCCESS)
         return set_err(SCARLET_E_HIP, "hipfftExecC2R failed");
@@ -866,11 +928,12 @@ extern "C" int scarlet_match_psfs(const float *psf1, int n, int P1y, int P1x, co
     while (Fx & 1) Fx = scarlet_next_fast_len(Fx + 1);
     const int64_t plane = (int64_t)Fy * Fx, splane = (int64_t)Fy * (Fx / 2 + 1);
     hipStream_t st = (hipStream_t)stream;
-    float *r1 = nullptr, *r2 = nullptr; float2 *s1 = nullptr, *s2 = nullptr;
-    HIP_TRY(hipMalloc((void **)&r1, n * plane * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&r2, n2 * plane * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&s1, n * splane * sizeof(float2)));
-    HIP_TRY(hipMalloc((void **)&s2, n2 * splane * sizeof(float2)));
+    DevBuf br1, br2, bs1, bs2;
+    DEV_ALLOC(br1, n * plane * sizeof(float));
+    DEV_ALLOC(br2, n2 * plane * sizeof(float));
+    DEV_ALLOC(bs1, n * splane * sizeof(float2));
+    DEV_ALLOC(bs2, n2 * splane * sizeof(float2));
+    float *r1 = br1.as<float>(), *r2 = br2.as<float>(); float2 *s1 = bs1.as<float2>(), *s2 = bs2.as<float2>();
     const int o1y = (Fy - P1y + 1) / 2 - Fy / 2, o1x = (Fx - P1x + 1) / 2 - Fx / 2;
     const int o2y = (Fy - P2y + 1) / 2 - Fy / 2, o2x = (Fx - P2x + 1) / 2 - Fx / 2;
     hipLaunchKernelGGL(k_plane_pad, dim3(grid_for(n * plane)), dim3(SC_BLOCK), 0, st, psf1, n, P1y, P1x, Fy, Fx, o1y, o1x, r1);
@@ -885,8 +948,7 @@ extern "C" int scarlet_match_psfs(const float *psf1, int n, int P1y, int P1x, co
             hipLaunchKernelGGL(k_plane_crop, dim3(grid_for((int64_t)n * P1y * P1x)), dim3(SC_BLOCK), 0, st,
                                (const float *)r1, n, P1y, P1x, Fy, Fx, o1y, o1x, out);
     }
-    const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);
-    (void)hipFree(r1); (void)hipFree(r2); (void)hipFree(s1); (void)hipFree(s2);
+    const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);    // buffers outlive the kernels
     if (rc) return rc;
     HIP_TRY(e1); HIP_TRY(e2);
     return SCARLET_OK;
@@ -900,27 +962,28 @@ extern "C" int scarlet_convolve_same(const float *model, int n, int H, int W, co
     const PsfGeom g = psf_geom(H, W, Py, Px);
     hipStream_t st = (hipStream_t)stream;
     const int64_t plane = (int64_t)g.Fy * g.Fx, splane = (int64_t)g.Fy * g.Fxh;
-    float *real = nullptr, *kreal = nullptr; float2 *spec = nullptr, *kspec = nullptr;
-    HIP_TRY(hipMalloc((void **)&real, n * plane * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&kreal, nk * plane * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&spec, n * splane * sizeof(float2)));
-    HIP_TRY(hipMalloc((void **)&kspec, nk * splane * sizeof(float2)));
+    DevBuf breal, bkreal, bspec, bkspec;
+    DEV_ALLOC(breal, n * plane * sizeof(float));
+    DEV_ALLOC(bkreal, nk * plane * sizeof(float));
+    DEV_ALLOC(bspec, n * splane * sizeof(float2));
+    DEV_ALLOC(bkspec, nk * splane * sizeof(float2));
+    float *real = breal.as<float>(), *kreal = bkreal.as<float>(); float2 *spec = bspec.as<float2>(), *kspec = bkspec.as<float2>();
     const int oky = (g.Fry - Py + 1) / 2 - g.Fry / 2, okx = (g.Frx - Px + 1) / 2 - g.Frx / 2;
     hipLaunchKernelGGL(k_plane_pad, dim3(grid_for(n * plane)), dim3(SC_BLOCK), 0, st, model, n, H, W, g.Fy, g.Fx, g.oy, g.ox, real);
     hipLaunchKernelGGL(k_psf_pad_kernel, dim3(grid_for(nk * plane)), dim3(SC_BLOCK), 0, st, kernel, nk, Py, Px, g.Fy, g.Fx, oky, okx, kreal);
     FftPlans pm, pk;
     int rc;
-    if ((rc = get_plans(g.Fy, g.Fx, n, &pm))) return rc;
-    if ((rc = get_plans(g.Fy, g.Fx, nk, &pk))) return rc;
-    if ((rc = fft_r2c(pm, real, spec, st))) return rc;
-    if ((rc = fft_r2c(pk, kreal, kspec, st))) return rc;
-    hipLaunchKernelGGL(k_spec_mul, dim3(grid_for(n * splane)), dim3(SC_BLOCK), 0, st, spec, kspec, nk, (int)splane,
-                       n * splane, 0, 1.0f / ((float)g.Fy * (float)g.Fx));
-    if ((rc = fft_c2r(pm, spec, real, st))) return rc;
-    hipLaunchKernelGGL(k_plane_crop, dim3(grid_for((int64_t)n * H * W)), dim3(SC_BLOCK), 0, st, real, n, H, W, g.Fy, g.Fx, g.oy, g.ox, out);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    (void)hipFree(real); (void)hipFree(kreal); (void)hipFree(spec); (void)hipFree(kspec);
+    if ((rc = get_plans(g.Fy, g.Fx, n, &pm)) == SCARLET_OK && (rc = get_plans(g.Fy, g.Fx, nk, &pk)) == SCARLET_OK &&
+        (rc = fft_r2c(pm, real, spec, st)) == SCARLET_OK && (rc = fft_r2c(pk, kreal, kspec, st)) == SCARLET_OK) {
+        hipLaunchKernelGGL(k_spec_mul, dim3(grid_for(n * splane)), dim3(SC_BLOCK), 0, st, spec, kspec, nk, (int)splane,
+                           n * splane, 0, 1.0f / ((float)g.Fy * (float)g.Fx));
+        if ((rc = fft_c2r(pm, spec, real, st)) == SCARLET_OK)
+            hipLaunchKernelGGL(k_plane_crop, dim3(grid_for((int64_t)n * H * W)), dim3(SC_BLOCK), 0, st, real, n, H, W,
+                               g.Fy, g.Fx, g.oy, g.ox, out);
+    }
+    const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);    // buffers outlive the kernels
+    if (rc) return rc;
+    HIP_TRY(e1); HIP_TRY(e2);
     return SCARLET_OK;
 }
 
@@ -988,8 +1051,8 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
     u.l0_thresh = b->l0_thresh; u.l1_thresh = b->l1_thresh;
     u.centroid_psf = b->centroid_psf; u.centroid_P = b->centroid_P; u.conv = ws_conv(b); u.force_it0 = force_it0;
     u.gscratch = nullptr;
-    u.hybrid_sweep = getenv("SCARLET_NO_HYBRID_SWEEP") ? 0 : 1;
-    if (b->H <= 64 && b->W <= 64 && !getenv("SCARLET_FORCE_BLOCK_UPDATE")) {
+    u.hybrid_sweep = opt(OPT_NO_HYBRID_SWEEP) ? 0 : 1;
+    if (b->H <= 64 && b->W <= 64 && !opt(OPT_FORCE_BLOCK_UPDATE)) {
         // one wave per component, four components per workgroup (wave_ops.h)
         const size_t lds = sizeof(float) * SC_NWAVES * ((size_t)b->H * tile_stride(b->W) + SC_WAVE_VEC_FLOATS);
         rc = allow_lds(k_source_update_w, lds);
@@ -1050,7 +1113,7 @@ static bool fused_ok(const scarlet_batch *b, int approximate_L)
 {
     // K > 4: eight tiles leave one workgroup per CU and the general path is faster (measured at K = 6, 8:
     // 2.44 vs 2.58 ms and 3.25 vs 3.90 ms per iteration of 4000 scenes)
-    if (approximate_L || b->diff_kernel || b->K > 4 || getenv("SCARLET_NO_FUSED")) return false;
+    if (approximate_L || b->diff_kernel || b->K > 4 || opt(OPT_NO_FUSED)) return false;
     if (b->H > 64 || b->W > 64 || (b->W & 3) || b->H < 3 || b->W < 3) return false;
     return fused_lds_bytes(b) <= LDS_LIMIT - 4096;
 }
@@ -1069,10 +1132,10 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
     f.symmetric = b->symmetric; f.monotonic = b->monotonic; f.l0_thresh = b->l0_thresh; f.l1_thresh = b->l1_thresh;
     f.centroid_psf = b->centroid_psf; f.centroid_P = b->centroid_P; f.e_rel2 = e_rel * e_rel;
     // diagnostics: SCARLET_STAMPS=1 writes phase stamps into the (otherwise unused) partials area
-    f.kscache = (b->diff_kernel || getenv("SCARLET_NO_KSCACHE")) ? nullptr : ws_kscache(b);
-    f.stamps = (getenv("SCARLET_STAMPS") && n_partials(b->K, b->B) >= 16) ? (long long *)ws_partials(b) : nullptr;
+    f.kscache = (b->diff_kernel || opt(OPT_NO_KSCACHE)) ? nullptr : ws_kscache(b);
+    f.stamps = (opt(OPT_STAMPS) && n_partials(b->K, b->B) >= 16) ? (long long *)ws_partials(b) : nullptr;
     // experiment knob: SCARLET_PAD_LDS=<bytes> lowers the number of co-resident workgroups
-    const size_t lds = fused_lds_bytes(b) + (getenv("SCARLET_PAD_LDS") ? (size_t)atoi(getenv("SCARLET_PAD_LDS")) : 0);
+    const size_t lds = fused_lds_bytes(b) + (size_t)opt(OPT_PAD_LDS);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_ITERATE(KM_, BM_)                                                                       \
     do {                                                                                               \
@@ -1084,9 +1147,9 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
     } while (0)
     // K <= 4, B <= 5: eight waves per scene, a pair of waves per component (fused2.h; its 128-VGPR
     // budget does not hold a sixth band's accumulators)
-    if (b->K <= 4 && b->B <= 5 && !getenv("SCARLET_FUSED_V1")) {
+    if (b->K <= 4 && b->B <= 5 && !opt(OPT_FUSED_V1)) {
         const size_t lds2 = sizeof(float) * ((size_t)b->K * b->H * tile_stride(b->W) + (size_t)b->K * SC_PAIR_VEC_FLOATS) +
-                            (getenv("SCARLET_PAD_LDS") ? (size_t)atoi(getenv("SCARLET_PAD_LDS")) : 0);
+                            (size_t)opt(OPT_PAD_LDS);
 #define LAUNCH_ITERATE2(BM_)                                                                           \
     do {                                                                                               \
         rc = allow_lds(k_iterate2<4, BM_>, lds2);                                                      \
@@ -1098,7 +1161,7 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
         // the headline shape (BASELINE configs[1]/[3]: 4 sources, 5 bands, 64 x 64, default pipeline) has
         // an instance with every shape and switch folded at compile time
         const bool exact64 = b->K == 4 && b->B == 5 && b->H == 64 && b->W == 64 && !b->weights && b->weight_scalar == 1.0f && b->symmetric &&
-                             b->monotonic && b->l0_thresh < 0.f && b->l1_thresh < 0.f && !getenv("SCARLET_NO_EXACT");
+                             b->monotonic && b->l0_thresh < 0.f && b->l1_thresh < 0.f && !opt(OPT_NO_EXACT);
         if (exact64) {
             rc = allow_lds(k_iterate2<4, 5, 64>, lds2);
             if (rc) return rc;
@@ -1277,7 +1340,7 @@ extern "C" int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host,
     a.morph[0] = b->morph[0]; a.morph[1] = b->morph[1]; a.cur = b->cur; a.centers = b->centers; a.flags = b->flags;
     a.has_scale = sed_scale_host != nullptr; a.thresh = thresh;
     a.do_symmetric = init_symmetric; a.do_monotonic = init_monotonic;
-    a.no_hybrid = getenv("SCARLET_NO_HYBRID_SWEEP") ? 1 : 0;
+    a.no_hybrid = opt(OPT_NO_HYBRID_SWEEP) ? 1 : 0;
     for (int i = 0; i < SC_BMAX; ++i) {
         a.bg_rms[i] = i < b->B ? (double)bg_rms_host[i] : 1.0;
         a.sed_scale[i] = (i < b->B && sed_scale_host) ? (double)sed_scale_host[i] : 1.0;
@@ -1292,12 +1355,11 @@ extern "C" int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host,
                            (double *)nullptr);
     } else {
         if (b->H > 256 || b->W > 256) return set_err(SCARLET_E_TOO_LARGE, "frames larger than 256 x 256 are not supported");
-        double *gtile = nullptr;                       // one-time setup: a temporary float64 tile per component
-        HIP_TRY(hipMalloc(&gtile, lds * (size_t)b->S * b->K));
-        hipLaunchKernelGGL(k_init_extended<true>, dim3(b->S * b->K), dim3(SC_BLOCK), 0, (hipStream_t)stream, a, gtile);
-        const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize((hipStream_t)stream);
-        (void)hipFree(gtile);
-        HIP_TRY(e1); HIP_TRY(e2);
+        DevBuf gtile;                                  // one-time setup: a temporary float64 tile per component
+        DEV_ALLOC(gtile, lds * (size_t)b->S * b->K);
+        hipLaunchKernelGGL(k_init_extended<true>, dim3(b->S * b->K), dim3(SC_BLOCK), 0, (hipStream_t)stream, a, gtile.as<double>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     }
     HIP_TRY(hipGetLastError());
     return run_update ? launch_update(b, 0, 1, stream) : SCARLET_OK;   // constructor's self.update()

@@ -312,8 +312,8 @@ def test_prior_hooks_match_the_oracle(scarlet):
     # and against the fixture produced by the reference itself (oracle/gen_golden.py gen_fit_extras)
     g = load_golden("fit_extras")
     assert rel_err(blend.mse, g["prior_mse"]) < 1e-5
-    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["prior_morph"]) < 2e-5
-    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["prior_sed"]) < 2e-5
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["prior_morph"]) < 1e-5
+    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["prior_sed"]) < 1e-5
     assert_array_equal(np.array([c.pixel_center for c in blend.components]), g["prior_center"])
     # the prior changed the fit of that component
     plain = pgm.scene_from_state(scn["images"], sed0, morph0, cen0, sh0)
@@ -363,8 +363,8 @@ def test_multicomponent_source_matches_the_oracle(scarlet):
     assert tuple(multi.pixel_center) == oms.center
     g = load_golden("fit_extras")                        # produced by the reference itself
     assert rel_err(blend.mse, g["multi_mse"]) < 1e-5
-    assert rel_err(np.array([npy(c.morph) for c in comps]), g["multi_morph"]) < 2e-5
-    assert rel_err(np.array([npy(c.sed) for c in comps]), g["multi_sed"]) < 2e-5
+    assert rel_err(np.array([npy(c.morph) for c in comps]), g["multi_morph"]) < 1e-5
+    assert rel_err(np.array([npy(c.sed) for c in comps]), g["multi_sed"]) < 1e-5
     assert_array_equal(np.array(multi.pixel_center), g["multi_center"])
 
 
@@ -393,8 +393,8 @@ def test_several_observations_match_the_reference(scarlet):
         blend.fit(8, e_rel=0)
         assert blend.it == 8
         assert rel_err(blend.mse, g[tag + "_mse"]) < 1e-5
-        assert rel_err(np.array([npy(c.morph) for c in blend.components]), g[tag + "_morph"]) < 2e-5
-        assert rel_err(np.array([npy(c.sed) for c in blend.components]), g[tag + "_sed"]) < 2e-5
+        assert rel_err(np.array([npy(c.morph) for c in blend.components]), g[tag + "_morph"]) < 1e-5
+        assert rel_err(np.array([npy(c.sed) for c in blend.components]), g[tag + "_sed"]) < 1e-5
         assert_array_equal(np.array([c.pixel_center for c in blend.components]), g[tag + "_center"])
 
 
@@ -416,8 +416,8 @@ def test_approximate_L_with_two_observations(scarlet):
     blend.fit(12, e_rel=0, approximate_L=True)
     assert blend.it == 12
     assert rel_err(blend.mse, g["mse"]) < 1e-5
-    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["morph"]) < 2e-5
-    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["sed"]) < 2e-5
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["morph"]) < 1e-5
+    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["sed"]) < 1e-5
     assert_array_equal(np.array([c.pixel_center for c in blend.components]), g["center"])
 
 
@@ -538,6 +538,6 @@ def test_combined_extended_source_matches_the_reference(scarlet):
     blend.fit(6, e_rel=0)
     assert blend.it == 6
     assert rel_err(blend.mse, g["mse"]) < 1e-5
-    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["morph"]) < 2e-5
-    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["sed"]) < 2e-5
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["morph"]) < 1e-5
+    assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["sed"]) < 1e-5
     assert_array_equal(np.array([c.pixel_center for c in blend.components]), g["center"])

@@ -148,10 +148,8 @@ def test_exact_shape_instance_is_bit_identical_to_the_generic_kernel(BB, monkeyp
     fix = np.zeros((S, 4), dtype=np.uint8)
     fix[::3, 1] = 1
     def run(generic, **kw):
-        if generic:
-            monkeypatch.setenv("SCARLET_NO_EXACT", "1")
-        else:
-            monkeypatch.delenv("SCARLET_NO_EXACT", raising=False)
+        from scarlet_amd import _lib
+        _lib.set_option("NO_EXACT", 1 if generic else 0)
         b = BB(data["images"], data["centers"])
         for name, arr in kw.items():
             setattr(b, name, torch.as_tensor(arr).cuda())
@@ -167,9 +165,12 @@ def test_exact_shape_instance_is_bit_identical_to_the_generic_kernel(BB, monkeyp
             np.testing.assert_array_equal(a, c)
     # the Hankel-vector cache of the k-space symmetry (workspace; vectors are recomputed only when
     # centre or shift changed) returns exactly what a fresh evaluation gives
-    monkeypatch.setenv("SCARLET_NO_KSCACHE", "1")
-    uncached = run(False)
-    monkeypatch.delenv("SCARLET_NO_KSCACHE")
+    from scarlet_amd import _lib
+    _lib.set_option("NO_KSCACHE", 1)
+    try:
+        uncached = run(False)
+    finally:
+        _lib.set_option("NO_KSCACHE", 0)
     for a, c in zip(uncached, run(False)):
         np.testing.assert_array_equal(a, c)
 
