@@ -549,6 +549,10 @@ class Source(object):
 def source_update(src, it):
     """PointSource.update (source.py:402-440): centre -> (every 5th it) centroid ->
     symmetric(kspace) -> monotonic(weighted) -> [sparse] -> positive -> morph_max."""
+    if getattr(src, "trace", None) is not None:
+        # test hook (tests/test_gpu_parity_long.py): the stepped morphology, i.e. what the k-space symmetry's
+        # `X <= 0` mask (operator.py:285-287) is about to see
+        src.trace["step"].append(src.morph.copy())
     src.center = max_pixel(src.morph, src.center)
     if src.symmetric:
         if it % 5 == 0:
@@ -562,8 +566,8 @@ def source_update(src, it):
     if src.l1_thresh is not None:
         prox_soft(src.morph, 1 / src.L_morph, src.l1_thresh)
     if getattr(src, "trace", None) is not None:
-        # test hook (tests/test_gpu_parity_long.py): the morphology as prox_plus is about to see it
-        src.trace.append(src.morph.copy())
+        # ... and the morphology as prox_plus is about to see it
+        src.trace["pre_plus"].append(src.morph.copy())
     prox_plus(src.sed)
     prox_plus(src.morph)
     normalize(src.sed, src.morph, "morph_max")

@@ -1,0 +1,516 @@
+// fftconv.h -- row a3b without a library FFT: Observation.render with a PSF difference kernel and its
+// adjoint (observation.py:198-239; fft.py:304-317, 264-279, 193-211, 138-181) as ONE kernel per
+// iteration.  A workgroup owns one (scene, band) plane and keeps its half-spectrum in LDS from the
+// model build to the gradient plane:
+//
+//   model_b = sum_k sed[k][b] morph[k]            (global -> LDS, rows 0..H-1, real pairs as complex)
+//   2-D real FFT, * K-hat_b, inverse              -> render_b                 (in LDS)
+//   d = w (render_b - image_b), loss_b; w d       (image streamed once from HBM)
+//   2-D real FFT, * conj K-hat_b, inverse         -> G_b = render^T(w d)      (LDS -> global, cropped)
+//
+// replacing k_psf_model + R2C + k_spec_mul + C2R + k_psf_resid + R2C + k_spec_mul + C2R of the
+// hipFFT chain (13 streaming passes over padded planes) by one read of the K morphologies and the
+// image and one write of G.
+//
+// The transform.  The reference pads to next_fast_len(N + P + 3) and crops (fft.py:68-106); the cropped
+// result is the LINEAR convolution, which any circular length F >= max(P + N - 1 + o, N - o) reproduces
+// (o = the kernel's offset (Fr - P + 1)//2 - Fr//2 <= 0 inside the reference's padded array -- it
+// decides which pixel of an even-sized kernel is its centre; scarlet_hip.hip fft_len_min()).  The image
+// sits at rows/columns 0..N-1 of the F-periodic plane, the kernel at (q + o) mod F, and the output is
+// read back at 0..N-1: pad, ifftshift, fftshift and crop of the reference collapse into that placement.
+//
+// 1-D engine: L = R1 * R2 with both radices <= 16, two passes IN PLACE (a thread writes only where it
+// read, so one barrier per pass and no ping-pong buffer):
+//   A  : for n2 < R2: radix-R1 DFT over x[R2 n1 + n2], times w_L^(n2 k1), stored at R2 k1 + n2
+//   B  : for k1 < R1: radix-R2 DFT over the R2 contiguous values, stored at R2 k1 + k2  = X[k1 + R1 k2]
+// The spectrum stays in that permuted order -- K-hat is produced by the same code, so the pointwise
+// product needs no reordering -- and the inverse runs B^-1 (conj twiddle after it), A^-1.
+// Real rows: z[n] = x[2n] + i x[2n+1] (a float2 load IS that packing), length-M = Fx/2 complex FFT,
+// then the pairs (k, M-k) are untangled in place; X[M] goes to an extra slot M of the row.
+// Radix codelets are straight-line register code generated from templates (constexpr twiddles).
+// tools/fft_proto.py is the numpy prototype of exactly this index algebra.
+#pragma once
+#include <type_traits>
+#include "common.h"
+#include "psf_path.h"
+
+// ------------------------------------------------------------------------------------------------
+// compile-time trigonometry for the codelets' internal twiddles
+constexpr double cx_pi = 3.141592653589793238462643383279502884;
+constexpr double cx_sin_series(double x)
+{   // |x| <= pi: 27 terms, error < 1e-15
+    double term = x, sum = x;
+    for (int n = 1; n < 27; ++n) { term *= -x * x / ((2 * n) * (2 * n + 1)); sum += term; }
+    return sum;
+}
+constexpr double cx_cos_series(double x)
+{
+    double term = 1, sum = 1;
+    for (int n = 1; n < 27; ++n) { term *= -x * x / ((2 * n - 1) * (2 * n)); sum += term; }
+    return sum;
+}
+// cos / sin of 2 pi num / den, num reduced to (-den/2, den/2]
+constexpr double cx_cos2pi(int num, int den)
+{
+    int r = ((num % den) + den) % den;
+    if (2 * r > den) r -= den;
+    return cx_cos_series(2 * cx_pi * r / den);
+}
+constexpr double cx_sin2pi(int num, int den)
+{
+    int r = ((num % den) + den) % den;
+    if (2 * r > den) r -= den;
+    return cx_sin_series(2 * cx_pi * r / den);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)     // a * conj(b)
+{
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// multiplication by -i (forward quarter turn) / +i
+template <bool INV> __device__ __forceinline__ float2 rot90(float2 a)
+{
+    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+// v * w_N^J (forward: e^{-2 pi i J / N}; INV: conjugate), J and N compile-time
+template <int N, int J, bool INV>
+__device__ __forceinline__ float2 twiddle_const(float2 v)
+{
+    constexpr int j = ((J % N) + N) % N;
+    if constexpr (j == 0) return v;
+    else if constexpr (4 * j == N) return rot90<INV>(v);
+    else if constexpr (2 * j == N) return make_float2(-v.x, -v.y);
+    else if constexpr (4 * j == 3 * N) return rot90<!INV>(v);
+    else {
+        constexpr float c = (float)cx_cos2pi(j, N);
+        constexpr float s = (float)(INV ? cx_sin2pi(j, N) : -cx_sin2pi(j, N));
+        return make_float2(v.x * c - v.y * s, v.x * s + v.y * c);
+    }
+}
+
+constexpr int first_factor(int n)
+{
+    if (n % 4 == 0 && n > 4) return 4;
+    if (n % 2 == 0) return 2;
+    if (n % 3 == 0) return 3;
+    if (n % 5 == 0) return 5;
+    if (n % 7 == 0) return 7;
+    return n;
+}
+
+// ---- radix codelets: in-register DFT of v[0..N-1], natural order in and out
+template <int N, bool INV> struct Dft;
+
+template <bool INV> struct Dft<1, INV> { static __device__ __forceinline__ void run(float2 (&)[1]) {} };
+template <bool INV> struct Dft<2, INV> {
+    static __device__ __forceinline__ void run(float2 (&v)[2])
+    {
+        const float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b); v[1] = csub(a, b);
+    }
+};
+template <bool INV> struct Dft<4, INV> {
+    static __device__ __forceinline__ void run(float2 (&v)[4])
+    {
+        const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = rot90<INV>(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2); v[2] = csub(t0, t2); v[1] = cadd(t1, t3); v[3] = csub(t1, t3);
+    }
+};
+// odd primes 3, 5, 7: pairs x_j +- x_{P-j}
+template <int P, bool INV> struct DftOddPrime {
+    static __device__ __forceinline__ void run(float2 (&v)[P])
+    {
+        constexpr int Hf = (P - 1) / 2;
+        float2 t[Hf], d[Hf];
+        static_for<0, Hf>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            t[j] = cadd(v[j + 1], v[P - 1 - j]);
+            d[j] = csub(v[j + 1], v[P - 1 - j]);
+        });
+        const float2 x0 = v[0];
+        float2 sum = x0;
+        static_for<0, Hf>([&](auto jc) { sum = cadd(sum, t[decltype(jc)::value]); });
+        v[0] = sum;
+        static_for<1, Hf + 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            float2 m = x0, n = make_float2(0.f, 0.f);
+            static_for<0, Hf>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr float c = (float)cx_cos2pi((j + 1) * k, P);
+                constexpr float s = (float)cx_sin2pi((j + 1) * k, P);
+                m.x += c * t[j].x; m.y += c * t[j].y;
+                n.x += s * d[j].x; n.y += s * d[j].y;
+            });
+            // forward: X_k = m - i n, X_{P-k} = m + i n
+            const float2 r = rot90<INV>(n);
+            v[k] = cadd(m, r);
+            v[P - k] = csub(m, r);
+        });
+    }
+};
+template <bool INV> struct Dft<3, INV> : DftOddPrime<3, INV> {};
+template <bool INV> struct Dft<5, INV> : DftOddPrime<5, INV> {};
+template <bool INV> struct Dft<7, INV> : DftOddPrime<7, INV> {};
+
+// composite N = A B (Cooley-Tukey in registers): n = B a + b, k = ka + A kb
+template <int N, bool INV> struct Dft {
+    static constexpr int A = first_factor(N), B = N / A;
+    static_assert(A > 1 && A < N, "unsupported radix");
+    static __device__ __forceinline__ void run(float2 (&v)[N])
+    {
+        float2 u[N];
+        static_for<0, B>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            float2 t[A];
+            static_for<0, A>([&](auto ac) { constexpr int a = decltype(ac)::value; t[a] = v[B * a + b]; });
+            Dft<A, INV>::run(t);
+            static_for<0, A>([&](auto kc) {
+                constexpr int ka = decltype(kc)::value;
+                u[ka * B + b] = twiddle_const<N, b * ka, INV>(t[ka]);
+            });
+        });
+        static_for<0, A>([&](auto kc) {
+            constexpr int ka = decltype(kc)::value;
+            float2 w[B];
+            static_for<0, B>([&](auto bc) { constexpr int b = decltype(bc)::value; w[b] = u[ka * B + b]; });
+            Dft<B, INV>::run(w);
+            static_for<0, B>([&](auto bc) { constexpr int kb = decltype(bc)::value; v[ka + A * kb] = w[kb]; });
+        });
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the plan: shapes, radices, placement; tables in device memory (built on the host in float64)
+#define SC_FFT_NT 512                   // threads of the convolution workgroup
+#define SC_FFT_MAXF 256
+struct FftPlan {
+    int H, W;                           // image
+    int Fy, Fx, M, RS;                  // transform lengths, M = Fx / 2, RS = row stride of the LDS plane in float2 (>= M + 1)
+    int R1y, R2y, R1x, R2x;             // Fy = R1y R2y, M = R1x R2x
+    int Py, Px, oky, okx;               // kernel shape and its offsets inside the periodic plane
+    float scale;                        // 1 / (M Fy): the two unnormalised inverse transforms
+    const float2 *tables;               // device: twy[Fy] = w_Fy^j, twm[M] = w_M^j, twx[M/2 + 1] = w_Fx^k, then posx[M] (uint16)
+};
+__host__ __device__ inline int fft_table_float2s(int Fy, int M) { return Fy + M + (M / 2 + 1) + (M + 3) / 4; }
+__host__ __device__ inline size_t fft_lds_bytes(int Fy, int M, int RS)
+{
+    return sizeof(float2) * ((size_t)Fy * RS + fft_table_float2s(Fy, M));
+}
+
+// exact u / d for 0 <= u < 2^20, 1 <= d < 2^12 (float reciprocal)
+__device__ __forceinline__ int fast_div(int u, float rcp_d) { return (int)(((float)u + 0.5f) * rcp_d); }
+
+// one pass over `nlines` independent 1-D transforms: item (line, j) loads v[q] = A[line*ls + j*joff + q*qs],
+// q < R, transforms, multiplies output k by (conj) tw[j k] when use_tw, and stores back in place.
+template <int R, bool INV>
+__device__ __forceinline__ void fft_items(float2 *A, int nlines, int ls, int J, int joff, int qs, const float2 *tw,
+                                          bool use_tw, bool line_fastest)
+{
+    const int total = nlines * J;
+    const float rcp = 1.0f / (float)(line_fastest ? nlines : J);
+    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+        int line, j;
+        if (line_fastest) { j = fast_div(u, rcp); line = u - j * nlines; }
+        else { line = fast_div(u, rcp); j = u - line * J; }
+        float2 *p = A + line * ls + j * joff;
+        float2 v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = p[q * qs];
+        Dft<R, INV>::run(v);
+        if (use_tw) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) {
+                const float2 w = tw[j * k];
+                v[k] = INV ? cmul_conj(v[k], w) : cmul(v[k], w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) p[q * qs] = v[q];
+    }
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft_pass(int R, float2 *A, int nlines, int ls, int J, int joff, int qs, const float2 *tw,
+                                         bool use_tw, bool line_fastest)
+{
+    switch (R) {
+#define SC_FFT_CASE(R_) case R_: fft_items<R_, INV>(A, nlines, ls, J, joff, qs, tw, use_tw, line_fastest); break;
+    SC_FFT_CASE(4) SC_FFT_CASE(5) SC_FFT_CASE(6) SC_FFT_CASE(7) SC_FFT_CASE(8) SC_FFT_CASE(9) SC_FFT_CASE(10)
+    SC_FFT_CASE(12) SC_FFT_CASE(14) SC_FFT_CASE(15) SC_FFT_CASE(16)
+#undef SC_FFT_CASE
+    default: break;
+    }
+    __syncthreads();
+}
+__host__ __device__ inline bool fft_radix_ok(int r)
+{
+    return r == 4 || r == 5 || r == 6 || r == 7 || r == 8 || r == 9 || r == 10 || r == 12 || r == 14 || r == 15 || r == 16;
+}
+
+// forward / inverse 1-D transforms of `nlines` lines (es = element stride, ls = line stride), in place
+__device__ __forceinline__ void fft_lines_fwd(float2 *A, int nlines, int ls, int es, int R1, int R2, const float2 *tw, bool lf)
+{
+    fft_pass<false>(R1, A, nlines, ls, R2, es, R2 * es, tw, true, lf);          // A
+    fft_pass<false>(R2, A, nlines, ls, R1, R2 * es, es, tw, false, lf);         // B
+}
+__device__ __forceinline__ void fft_lines_inv(float2 *A, int nlines, int ls, int es, int R1, int R2, const float2 *tw, bool lf)
+{
+    fft_pass<true>(R2, A, nlines, ls, R1, R2 * es, es, tw, true, lf);           // B^-1
+    fft_pass<true>(R1, A, nlines, ls, R2, es, R2 * es, tw, false, lf);          // A^-1
+}
+
+struct FftLds {
+    float2 *A;                  // [Fy][RS]
+    const float2 *twy, *twm, *twx;
+    const unsigned short *posx;
+};
+__device__ __forceinline__ FftLds fft_lds_setup(float2 *lds, const FftPlan &p)
+{
+    FftLds l;
+    l.A = lds;
+    float2 *t = lds + (size_t)p.Fy * p.RS;
+    const int nt = fft_table_float2s(p.Fy, p.M);
+    for (int i = threadIdx.x; i < nt; i += SC_FFT_NT) t[i] = p.tables[i];
+    l.twy = t; l.twm = t + p.Fy; l.twx = l.twm + p.M;
+    l.posx = (const unsigned short *)(l.twx + (p.M / 2 + 1));
+    return l;
+}
+
+// real rows after the length-M complex FFT: untangle the pairs (k, M - k) in place (tools/fft_proto.py rows_fwd)
+__device__ __forceinline__ void fft_rows_untangle(const FftLds &l, const FftPlan &p, int nrows)
+{
+    const int M = p.M, half = M / 2 + 1;          // k = 0 .. M/2
+    const int total = nrows * half;
+    const float rcp = 1.0f / (float)half;
+    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+        const int y = fast_div(u, rcp), k = u - y * half;
+        float2 *r = l.A + y * p.RS;
+        if (k == 0) {
+            const float2 z = r[l.posx[0]];
+            r[l.posx[0]] = make_float2(z.x + z.y, 0.f);
+            r[M] = make_float2(z.x - z.y, 0.f);
+        } else if (2 * k == M) {
+            const int q = l.posx[k];
+            r[q] = cconj(r[q]);
+        } else if (2 * k < M) {
+            const int pa = l.posx[k], pb = l.posx[M - k];
+            const float2 a = r[pa], b = r[pb], w = l.twx[k];
+            // X[k] = (a + b*)/2 - i/2 w (a - b*);  X[M-k] = (b + a*)/2 + i/2 w* (b - a*)
+            const float2 s = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));     // (a + b*)/2
+            const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));     // (a - b*)/2
+            const float2 wd = cmul(w, d);                                              // w d ; -i (wd) = (wd.y, -wd.x)
+            r[pa] = make_float2(s.x + wd.y, s.y - wd.x);
+            // (b + a*)/2 = conj(s);  (b - a*)/2 = -conj(d);  + i w* (-conj d) = -i conj(w d) = -i (wd.x, -wd.y) = (-wd.y, -wd.x)
+            r[pb] = make_float2(s.x - wd.y, -s.y - wd.x);
+        }
+    }
+    __syncthreads();
+}
+// inverse of fft_rows_untangle (tools/fft_proto.py rows_inv)
+__device__ __forceinline__ void fft_rows_tangle(const FftLds &l, const FftPlan &p, int nrows)
+{
+    const int M = p.M, half = M / 2 + 1;
+    const int total = nrows * half;
+    const float rcp = 1.0f / (float)half;
+    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+        const int y = fast_div(u, rcp), k = u - y * half;
+        float2 *r = l.A + y * p.RS;
+        if (k == 0) {
+            const float x0 = r[l.posx[0]].x, xm = r[M].x;
+            r[l.posx[0]] = make_float2(0.5f * (x0 + xm), 0.5f * (x0 - xm));
+        } else if (2 * k == M) {
+            const int q = l.posx[k];
+            r[q] = cconj(r[q]);
+        } else if (2 * k < M) {
+            const int pa = l.posx[k], pb = l.posx[M - k];
+            const float2 xk = r[pa], xm = r[pb], w = l.twx[k];
+            const float2 E = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));      // (X[k] + X[M-k]*)/2
+            const float2 D = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));      // (X[k] - X[M-k]*)/2
+            const float2 O = cmul_conj(D, w);                                              // D conj(w)
+            // Z[k] = E + i O ; Z[M-k] = conj(E) + i conj(O)
+            r[pa] = make_float2(E.x - O.y, E.y + O.x);
+            r[pb] = make_float2(E.x + O.y, -E.y + O.x);
+        }
+    }
+    __syncthreads();
+}
+
+// 2-D forward / inverse on the plane in LDS; rows < nrows_in hold data (the others are zero on input /
+// not needed on output)
+__device__ __forceinline__ void fft2d_fwd(const FftLds &l, const FftPlan &p, int nrows)
+{
+    fft_lines_fwd(l.A, nrows, p.RS, 1, p.R1x, p.R2x, l.twm, false);
+    fft_rows_untangle(l, p, nrows);
+    fft_lines_fwd(l.A, p.M + 1, 1, p.RS, p.R1y, p.R2y, l.twy, true);
+}
+__device__ __forceinline__ void fft2d_inv(const FftLds &l, const FftPlan &p, int nrows)
+{
+    fft_lines_inv(l.A, p.M + 1, 1, p.RS, p.R1y, p.R2y, l.twy, true);
+    fft_rows_tangle(l, p, nrows);
+    fft_lines_inv(l.A, nrows, p.RS, 1, p.R1x, p.R2x, l.twm, false);
+}
+// A *= (conj) K-hat (already scaled), all Fy x (M + 1) slots; K-hat [Fy][M + 1] in global memory
+template <bool CONJ>
+__device__ __forceinline__ void fft_spec_mul(const FftLds &l, const FftPlan &p, const float2 *khat)
+{
+    const int cols = p.M + 1, total = p.Fy * cols;
+    const float rcp = 1.0f / (float)cols;
+    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+        const int y = fast_div(u, rcp), c = u - y * cols;
+        const float2 k = khat[u];
+        float2 *q = l.A + y * p.RS + c;
+        *q = CONJ ? cmul_conj(*q, k) : cmul(*q, k);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-hat: one workgroup per kernel plane.  kernel [nk][Py][Px] -> khat [nk][Fy][M + 1] (permuted, scaled)
+__global__ __launch_bounds__(SC_FFT_NT) void k_fft_khat(const float *ker, FftPlan p, float2 *khat)
+{
+    extern __shared__ __align__(16) float2 fft_lds[];
+    const FftLds l = fft_lds_setup(fft_lds, p);
+    const int plane = blockIdx.x;
+    const float *kp = ker + (size_t)plane * p.Py * p.Px;
+    const int M = p.M, cols = M + 1;
+    for (int u = threadIdx.x; u < p.Fy * p.RS; u += SC_FFT_NT) {
+        const int iy = u / p.RS, n = u - iy * p.RS;
+        float2 v = make_float2(0.f, 0.f);
+        if (n < M) {
+            const int q = pos_mod(iy - p.oky, p.Fy);
+            if (q < p.Py) {
+                const int r0 = pos_mod(2 * n - p.okx, p.Fx), r1 = pos_mod(2 * n + 1 - p.okx, p.Fx);
+                if (r0 < p.Px) v.x = kp[q * p.Px + r0];
+                if (r1 < p.Px) v.y = kp[q * p.Px + r1];
+            }
+        }
+        l.A[u] = v;
+    }
+    __syncthreads();
+    fft2d_fwd(l, p, p.Fy);
+    float2 *out = khat + (size_t)plane * p.Fy * cols;
+    for (int u = threadIdx.x; u < p.Fy * cols; u += SC_FFT_NT) {
+        const int y = u / cols, c = u - y * cols;
+        const float2 v = l.A[y * p.RS + c];
+        out[u] = make_float2(v.x * p.scale, v.y * p.scale);
+    }
+}
+
+// standalone render of n planes (Observation.render / scarlet_convolve_same): out = crop(in (*) kernel)
+__global__ __launch_bounds__(SC_FFT_NT) void k_fft_convolve(const float *in, FftPlan p, const float2 *khat, int nk, float *out)
+{
+    extern __shared__ __align__(16) float2 fft_lds[];
+    const FftLds l = fft_lds_setup(fft_lds, p);
+    const int plane = blockIdx.x, H = p.H, W = p.W, M = p.M, Wh = (W + 1) / 2;
+    const float *ip = in + (size_t)plane * H * W;
+    for (int u = threadIdx.x; u < p.Fy * p.RS; u += SC_FFT_NT) {
+        const int y = u / p.RS, n = u - y * p.RS;
+        float2 v = make_float2(0.f, 0.f);
+        if (y < H && n < Wh) {
+            v.x = ip[y * W + 2 * n];
+            if (2 * n + 1 < W) v.y = ip[y * W + 2 * n + 1];
+        }
+        l.A[u] = v;
+    }
+    __syncthreads();
+    fft2d_fwd(l, p, H);
+    fft_spec_mul<false>(l, p, khat + (size_t)(nk == 1 ? 0 : plane) * p.Fy * (M + 1));
+    fft2d_inv(l, p, H);
+    float *op = out + (size_t)plane * H * W;
+    for (int u = threadIdx.x; u < H * W; u += SC_FFT_NT) {
+        const int y = u / W, x = u - y * W;
+        const float2 v = l.A[y * p.RS + (x >> 1)];
+        op[u] = (x & 1) ? v.y : v.x;
+    }
+}
+
+// the iteration's convolution pair: G_b = render^T( w^2 (render(model)_b - image_b) ), loss_b
+// grid: one workgroup per (scene, band), XCD-aware: the B planes of a scene share an XCD (their morphology
+// reads meet in that XCD's L2), consecutive scenes go to consecutive XCDs.
+__global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, float *G)
+{
+    extern __shared__ __align__(16) float2 fft_lds[];
+    const int B = a.B, K = a.K;
+    const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    const int grp = t / B, b = t - grp * B, s = grp * 8 + xcd;
+    if (s >= a.S || !a.active[s]) return;
+    const FftLds l = fft_lds_setup(fft_lds, p);
+    __shared__ float sed_s[SC_KBIG];
+    __shared__ double red[SC_FFT_NT / SC_WAVE];
+    const int H = p.H, W = p.W, M = p.M, HW = H * W, Wh = W >> 1;           // W even (checked on the host)
+    const int c0 = a.cur[s];
+    for (int k = threadIdx.x; k < K; k += SC_FFT_NT) sed_s[k] = a.sed[c0][((size_t)s * K + k) * B + b];
+    __syncthreads();
+    // model_b into rows < H (pairs of pixels), zeros elsewhere
+    const float *mor = a.morph[c0] + (size_t)s * K * HW;
+    for (int u = threadIdx.x; u < p.Fy * p.RS; u += SC_FFT_NT) {
+        const int y = u / p.RS, n = u - y * p.RS;
+        float2 v = make_float2(0.f, 0.f);
+        if (y < H && n < Wh) {
+            const float2 *mp = (const float2 *)(mor + y * W) + n;
+            for (int k = 0; k < K; ++k) {
+                const float2 m = mp[(size_t)k * (HW / 2)];
+                const float sk = sed_s[k];
+                v.x += sk * m.x; v.y += sk * m.y;
+            }
+        }
+        l.A[u] = v;
+    }
+    __syncthreads();
+    const float2 *khat = a.khat + (size_t)(a.khat_per_scene ? s * B + b : b) * p.Fy * (M + 1);
+    fft2d_fwd(l, p, H);
+    fft_spec_mul<false>(l, p, khat);
+    fft2d_inv(l, p, H);
+    // residual: d = w (render - image); loss; w d back into the plane, zeros around it
+    const size_t plane = (size_t)s * B + b;
+    const float2 *img = (const float2 *)(a.images + plane * HW);
+    const float2 *wgt = a.weights ? (const float2 *)(a.weights + plane * HW) : nullptr;
+    double loss = 0;
+    for (int u = threadIdx.x; u < p.Fy * p.RS; u += SC_FFT_NT) {
+        const int y = u / p.RS, n = u - y * p.RS;
+        float2 v = make_float2(0.f, 0.f);
+        if (y < H && n < Wh) {
+            const float2 r = l.A[u], im = img[y * Wh + n];
+            const float2 w = wgt ? wgt[y * Wh + n] : make_float2(a.weight_scalar, a.weight_scalar);
+            const float dx = w.x * (r.x - im.x), dy = w.y * (r.y - im.y);
+            loss += (double)dx * (double)dx + (double)dy * (double)dy;
+            v = make_float2(w.x * dx, w.y * dy);
+        }
+        l.A[u] = v;
+    }
+    __syncthreads();
+    fft2d_fwd(l, p, H);
+    fft_spec_mul<true>(l, p, khat);
+    fft2d_inv(l, p, H);
+    float2 *gp = (float2 *)(G + plane * HW);
+    for (int u = threadIdx.x; u < H * Wh; u += SC_FFT_NT) {
+        const int y = u / Wh, n = u - y * Wh;
+        gp[u] = l.A[y * p.RS + n];
+    }
+    // loss of the plane
+    loss = wave_sum(loss);
+    if ((threadIdx.x & (SC_WAVE - 1)) == 0) red[threadIdx.x / SC_WAVE] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0;
+        for (int w = 0; w < SC_FFT_NT / SC_WAVE; ++w) r += red[w];
+        a.loss_part[plane] = 0.5 * r;
+    }
+}

@@ -42,7 +42,8 @@ struct PsfArgs {
     const uint8_t *fix_sed, *fix_morph;
     float *real;                 // [S*B][Fy][Fx]
     float2 *spec;                // [S*B][Fy][Fxh]
-    const float2 *khat;          // [B][Fy][Fxh]
+    const float2 *khat;          // [B][Fy][Fxh] (or [S*B]...: khat_per_scene)
+    int khat_per_scene;
     double *partials;            // [S][T][P] (sed gradient + Gram) ; loss in loss_part
     double *loss_part;           // [S][B]
     double *lipschitz, *mse;

@@ -20,6 +20,7 @@
 #include "fused2.h"
 #include "bigk.h"
 #include "psf_path.h"
+#include "fftconv.h"
 #include "extras.h"
 
 __constant__ unsigned short sc_nfl_table[SC_NFL_MAX];
@@ -724,17 +725,91 @@ static int64_t base_workspace_bytes(const scarlet_batch *b)
     return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4)) + resid +
            gscratch_bytes(b) + kscache_bytes(b) + 256;
 }
-struct PsfLayout { int64_t loss, real, spec, khat, total; };
+// ---- LDS-resident convolution (fftconv.h): plan = lengths, radices, kernel placement
+// smallest circular length that reproduces the cropped linear convolution: image at 0..N-1, kernel at
+// (q + o) mod F, output read at 0..N-1 (o <= 0 is the kernel's offset in the reference's padded array)
+static int fft_len_min(int N, int P, int o)
+{
+    int m = P + N - 1 + o;
+    if (N - o > m) m = N - o;
+    if (N > m) m = N;
+    if (P > m) m = P;
+    return m;
+}
+// smallest L = r1 r2 >= Lmin with both radices on the menu; ties: odd r2 first when `prefer_odd_r2`
+// (the contiguous run of pass B, bank conflicts), then the more balanced pair
+static bool fft_choose(int Lmin, bool prefer_odd_r2, int *L, int *r1, int *r2)
+{
+    static const int menu[] = {4, 5, 6, 7, 8, 9, 10, 12, 14, 15, 16};
+    long best = -1;
+    for (int a : menu)
+        for (int b : menu) {
+            const int l = a * b;
+            if (l < Lmin) continue;
+            const int bal = a > b ? a - b : b - a;
+            const long score = (long)l * 1000 + ((prefer_odd_r2 && !(b & 1)) ? 100 : 0) + bal;
+            if (best < 0 || score < best) { best = score; *L = l; *r1 = a; *r2 = b; }
+        }
+    return best >= 0;
+}
+// plan for an H x W image and a Py x Px kernel; false when no menu length fits or the plane exceeds LDS
+static bool fft_make_plan(int H, int W, int Py, int Px, FftPlan *p)
+{
+    const PsfGeom g = psf_geom(H, W, Py, Px);         // reference FFT shape -> kernel offsets
+    const int oky = (g.Fry - Py + 1) / 2 - g.Fry / 2, okx = (g.Frx - Px + 1) / 2 - g.Frx / 2;
+    const int Fy_min = fft_len_min(H, Py, oky), Fx_min = fft_len_min(W, Px, okx);
+    int Fy, M, r1y, r2y, r1x, r2x;
+    if (!fft_choose(Fy_min, false, &Fy, &r1y, &r2y)) return false;
+    if (!fft_choose((Fx_min + 1) / 2, true, &M, &r1x, &r2x)) return false;
+    p->H = H; p->W = W; p->Fy = Fy; p->Fx = 2 * M; p->M = M; p->RS = M + 1;
+    p->R1y = r1y; p->R2y = r2y; p->R1x = r1x; p->R2x = r2x;
+    p->Py = Py; p->Px = Px; p->oky = oky; p->okx = okx;
+    p->scale = (float)(1.0 / ((double)M * (double)Fy));
+    p->tables = nullptr;
+    return fft_lds_bytes(Fy, M, p->RS) <= LDS_LIMIT - 4096;
+}
+// twiddle / permutation tables of a plan, float64 -> float32 (layout: fftconv.h FftPlan::tables)
+static void fft_fill_tables(const FftPlan &p, std::vector<float2> &t)
+{
+    const double tau = 6.283185307179586476925286766559;
+    t.assign(fft_table_float2s(p.Fy, p.M), make_float2(0.f, 0.f));
+    float2 *twy = t.data(), *twm = twy + p.Fy, *twx = twm + p.M;
+    for (int j = 0; j < p.Fy; ++j) twy[j] = make_float2((float)cos(tau * j / p.Fy), (float)-sin(tau * j / p.Fy));
+    for (int j = 0; j < p.M; ++j) twm[j] = make_float2((float)cos(tau * j / p.M), (float)-sin(tau * j / p.M));
+    for (int k = 0; k <= p.M / 2; ++k) twx[k] = make_float2((float)cos(tau * k / p.Fx), (float)-sin(tau * k / p.Fx));
+    unsigned short *posx = (unsigned short *)(twx + (p.M / 2 + 1));
+    for (int k = 0; k < p.M; ++k) posx[k] = (unsigned short)(p.R2x * (k % p.R1x) + k / p.R1x);
+}
+static bool psf_lds_possible(const scarlet_batch *b, FftPlan *p)
+{
+    FftPlan tmp;
+    if (!p) p = &tmp;
+    if (b->W & 1) return false;                       // k_psf_conv reads pixel pairs (float2)
+    return fft_make_plan(b->H, b->W, b->psf_h, b->psf_w, p);
+}
+
+// Workspace of a batch with a PSF.  Which convolution runs is a function of the shapes alone -- the
+// LDS-resident transform whenever the half-spectrum plane fits LDS, batched hipFFT otherwise (frames
+// beyond ~150 + P pixels) -- except for the diagnostic switch PSF_HIPFFT, which forces the library path
+// and must not change during the life of a batch (it is read when the workspace is sized).
+static bool psf_use_lds(const scarlet_batch *b, FftPlan *p) { return psf_lds_possible(b, p) && !opt(OPT_PSF_HIPFFT); }
+struct PsfLayout { int64_t loss, real, spec, khat, lds_khat, lds_tables, total; };
 static PsfLayout psf_layout(const scarlet_batch *b)
 {
     const PsfGeom g = psf_geom(b->H, b->W, b->psf_h, b->psf_w);
     const int64_t planes = (int64_t)b->S * b->B;
+    const int64_t nk = b->diff_kernel_per_scene ? planes : (int64_t)b->B;
+    FftPlan p;
+    const bool lds = psf_use_lds(b, &p), want_hipfft = !lds;
     PsfLayout l;
     l.loss = base_workspace_bytes(b);
     l.real = l.loss + align256(planes * (int64_t)sizeof(double));
-    l.spec = l.real + align256(planes * g.Fy * g.Fx * (int64_t)sizeof(float));
-    l.khat = l.spec + align256(planes * g.Fy * g.Fxh * (int64_t)sizeof(float2));
-    l.total = l.khat + align256((b->diff_kernel_per_scene ? planes : (int64_t)b->B) * g.Fy * g.Fxh * (int64_t)sizeof(float2));
+    // `real`: padded FFT planes (hipFFT path) or the compact gradient planes G [S][B][H][W] (LDS path)
+    l.spec = l.real + align256(planes * (want_hipfft ? (int64_t)g.Fy * g.Fx : (int64_t)b->H * b->W) * (int64_t)sizeof(float));
+    l.khat = l.spec + (want_hipfft ? align256(planes * g.Fy * g.Fxh * (int64_t)sizeof(float2)) : 0);
+    l.lds_khat = l.khat + (want_hipfft ? align256(nk * g.Fy * g.Fxh * (int64_t)sizeof(float2)) : 0);
+    l.lds_tables = l.lds_khat + (lds ? align256(nk * p.Fy * (p.M + 1) * (int64_t)sizeof(float2)) : 0);
+    l.total = l.lds_tables + (lds ? align256(fft_table_float2s(p.Fy, p.M) * (int64_t)sizeof(float2)) : 0) + 256;
     return l;
 }
 
@@ -828,10 +903,26 @@ extern "C" int scarlet_batch_prepare_psf(scarlet_batch *b, void *stream)
     const PsfGeom g = psf_geom(b->H, b->W, b->psf_h, b->psf_w);
     const PsfLayout l = psf_layout(b);
     hipStream_t st = (hipStream_t)stream;
+    const int nk = b->diff_kernel_per_scene ? b->S * b->B : b->B;
+    FftPlan fp;
+    if (psf_use_lds(b, &fp)) {
+        // LDS-resident transform (fftconv.h): tables, then K-hat by the same forward code as the iteration
+        std::vector<float2> tab;
+        fft_fill_tables(fp, tab);
+        float2 *dtab = (float2 *)((char *)b->workspace + l.lds_tables);
+        HIP_TRY(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));            // `tab` is host memory of this call
+        fp.tables = dtab;
+        const size_t lds = fft_lds_bytes(fp.Fy, fp.M, fp.RS);
+        if ((rc = allow_lds(k_fft_khat, lds))) return rc;
+        hipLaunchKernelGGL(k_fft_khat, dim3(nk), dim3(SC_FFT_NT), lds, st, b->diff_kernel, fp,
+                           (float2 *)((char *)b->workspace + l.lds_khat));
+        HIP_TRY(hipGetLastError());
+        return SCARLET_OK;
+    }
     float *real = (float *)((char *)b->workspace + l.real);
     float2 *khat = (float2 *)((char *)b->workspace + l.khat);
     const int oky = (g.Fry - b->psf_h + 1) / 2 - g.Fry / 2, okx = (g.Frx - b->psf_w + 1) / 2 - g.Frx / 2;
-    const int nk = b->diff_kernel_per_scene ? b->S * b->B : b->B;
     hipLaunchKernelGGL(k_psf_pad_kernel, dim3(grid_for((int64_t)nk * g.Fy * g.Fx)), dim3(SC_BLOCK), 0, st,
                        b->diff_kernel, nk, b->psf_h, b->psf_w, g.Fy, g.Fx, oky, okx, real);
     FftPlans pk;
@@ -863,8 +954,25 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
     const int plane_elems = g.Fy * g.Fxh;
     const float scale = 1.0f / ((float)g.Fy * (float)g.Fx);
     const int nkh = b->diff_kernel_per_scene ? planes : b->B;
+    a.khat_per_scene = b->diff_kernel_per_scene;
+    int rc;
+    FftPlan fp;
+    const bool lds_path = psf_use_lds(b, &fp);
+    if (lds_path) {
+        // one kernel: model, render, residual + loss, adjoint -> compact gradient planes G [S][B][H][W] in `real`
+        fp.tables = (const float2 *)((char *)b->workspace + l.lds_tables);
+        a.khat = (const float2 *)((char *)b->workspace + l.lds_khat);
+        const size_t lds = fft_lds_bytes(fp.Fy, fp.M, fp.RS);
+        if ((rc = allow_lds(k_psf_conv, lds))) return rc;
+        const int groups = (b->S + 7) / 8;
+        prof_start(5, st);
+        hipLaunchKernelGGL(k_psf_conv, dim3(groups * 8 * b->B), dim3(SC_FFT_NT), lds, st, a, fp, a.real);
+        prof_stop(st);
+        // the gradient kernels below read G through the same geometry struct: compact planes, no offset
+        a.g.Fy = b->H; a.g.Fx = b->W; a.g.Fxh = b->W / 2 + 1; a.g.oy = 0; a.g.ox = 0;
+    } else {
     FftPlans p;
-    int rc = get_plans(g.Fy, g.Fx, planes, &p);
+    rc = get_plans(g.Fy, g.Fx, planes, &p);
     if (rc) return rc;
     prof_start(5, st);
     hipLaunchKernelGGL(k_psf_model, dim3((g.Fy * g.Fx + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
@@ -878,15 +986,18 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
                        a.spec, a.khat, nkh, plane_elems, (int64_t)planes * plane_elems, 1, scale);
     if ((rc = fft_c2r(p, a.spec, a.real, st))) return rc;
     prof_stop(st);
+    }
     dim3 grid(a.T, a.S);
     if (b->K > SC_KMAX) {
-        // many components: G is cropped out of the FFT buffers once, then the chunked passes of bigk.h
+        // many components: G is cropped out of the FFT buffers once (the LDS path's planes are compact already),
+        // then the chunked passes of bigk.h
         GradArgs ga = grad_args(b, approximate_L, raw_gradient);
-        float *resid = ws_resid(b);
+        float *resid = lds_path ? a.real : ws_resid(b);
         const int nch = (b->K + SC_CHUNK - 1) / SC_CHUNK;
         prof_start(0, st);
-        hipLaunchKernelGGL(k_plane_crop, dim3(grid_for((int64_t)planes * b->H * b->W)), dim3(SC_BLOCK), 0, st,
-                           (const float *)a.real, planes, b->H, b->W, g.Fy, g.Fx, g.oy, g.ox, resid);
+        if (!lds_path)
+            hipLaunchKernelGGL(k_plane_crop, dim3(grid_for((int64_t)planes * b->H * b->W)), dim3(SC_BLOCK), 0, st,
+                               (const float *)a.real, planes, b->H, b->W, g.Fy, g.Fx, g.oy, g.ox, resid);
         hipLaunchKernelGGL(k_bigk_loss_from_planes, dim3((b->S + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0, st, ga,
                            (const double *)a.loss_part);
         hipLaunchKernelGGL(k_bigk_gram, dim3(ga.T, nch * (nch + 1) / 2, ga.S), dim3(SC_BLOCK), 0, st, ga);
@@ -961,6 +1072,25 @@ extern "C" int scarlet_convolve_same(const float *model, int n, int H, int W, co
         return set_err(SCARLET_E_ARG, "bad convolve arguments");
     const PsfGeom g = psf_geom(H, W, Py, Px);
     hipStream_t st = (hipStream_t)stream;
+    FftPlan fp;
+    if (fft_make_plan(H, W, Py, Px, &fp) && !opt(OPT_PSF_HIPFFT)) {
+        // LDS-resident transform (fftconv.h), one workgroup per plane
+        std::vector<float2> tab;
+        fft_fill_tables(fp, tab);
+        DevBuf dtab, dkhat;
+        DEV_ALLOC(dtab, tab.size() * sizeof(float2));
+        DEV_ALLOC(dkhat, (size_t)nk * fp.Fy * (fp.M + 1) * sizeof(float2));
+        HIP_TRY(hipMemcpy(dtab.p, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+        fp.tables = dtab.as<float2>();
+        const size_t lds = fft_lds_bytes(fp.Fy, fp.M, fp.RS);
+        int rc;
+        if ((rc = allow_lds(k_fft_khat, lds)) || (rc = allow_lds(k_fft_convolve, lds))) return rc;
+        hipLaunchKernelGGL(k_fft_khat, dim3(nk), dim3(SC_FFT_NT), lds, st, kernel, fp, dkhat.as<float2>());
+        hipLaunchKernelGGL(k_fft_convolve, dim3(n), dim3(SC_FFT_NT), lds, st, model, fp, (const float2 *)dkhat.as<float2>(), nk, out);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));            // the temporaries outlive the kernels
+        return SCARLET_OK;
+    }
     const int64_t plane = (int64_t)g.Fy * g.Fx, splane = (int64_t)g.Fy * g.Fxh;
     DevBuf breal, bkreal, bspec, bkspec;
     DEV_ALLOC(breal, n * plane * sizeof(float));

@@ -4,16 +4,19 @@ run to convergence at e_rel = 1e-3 (ragged stop, 3 .. ~150 iterations) -- GPU en
 oracle started from the device's own initial state.  Tolerance: north_star's 1e-5 max-norm relative
 for sed / morph / loss history; centres, iteration counts and flags bit-exact.
 
-The algorithm has one discontinuity, prox_plus (x < 0 -> 0, update.py:27-32 via proxmin): a pixel
-whose stepped value sits on the threshold to within float32 rounding can land on either side, and
-after it switches on it grows for a few iterations before the two runs meet again.  Such a scene is
-NOT waived in prose: `straddles_threshold` re-runs it iteration by iteration on the GPU, in the
-float32 oracle and in the float64 oracle and accepts it only if, mechanically,
+The algorithm tests pixel values against the threshold 0 in two places: the k-space symmetry zeroes
+its output wherever its INPUT, the stepped morphology, is <= 0 (`result[X <= 0] = 0`,
+operator.py:285-287) -- a jump: just above 0 the output is the average with the mirrored pixel -- and
+prox_plus (update.py:27-32).  A pixel whose value sits on the threshold to within float32 rounding
+can land on either side; after it switches on it differs for a few iterations before the two runs meet
+again.  Such a scene is NOT waived in prose: `straddles_threshold` re-runs it iteration by iteration on
+the GPU, in the float32 oracle and in the float64 oracle and accepts it only if, mechanically,
   (i)   GPU and float32 oracle agree within 1e-5 on every array at every iteration before t0,
   (ii)  at t0 they disagree about the SUPPORT of the morphology in some pixel p (one is exactly 0), and
-  (iii) the float64 trajectory's value at p as prox_plus is about to see it at t0 lies within
-        1e-5 x max|morph| of the threshold 0 -- i.e. the exact trajectory itself is undecided at the
-        tolerance, so both outcomes are admissible float32 evaluations of the reference.
+  (iii) the float64 trajectory's value at p at one of the two threshold tests of iteration t0 (the
+        stepped value entering the symmetry mask, or the value entering prox_plus) lies within
+        1e-5 x max|morph| of 0 -- i.e. the exact trajectory itself is undecided at the tolerance, so
+        both outcomes are admissible float32 evaluations of the reference.
 """
 import multiprocessing as mp
 import os
@@ -44,10 +47,11 @@ def _oracle_trace(images, sed0, morph0, cen0, sh0, iters, dt):
     from oracle import pgm
     sc = pgm.scene_from_state(images.astype(dt), sed0.astype(dt), morph0.astype(dt), cen0, sh0)
     for s in sc.sources:
-        s.trace = []
+        s.trace = dict(step=[], pre_plus=[])
     post = []
     pgm.fit(sc, iters, e_rel=0, callback=lambda scn: post.append(np.array([s.morph.copy() for s in scn.sources])))
-    pre = [np.array([s.trace[t] for s in sc.sources]) for t in range(iters)]
+    pre = [(np.array([s.trace["step"][t] for s in sc.sources]), np.array([s.trace["pre_plus"][t] for s in sc.sources]))
+           for t in range(iters)]
     return post, pre
 
 
@@ -95,12 +99,14 @@ def straddles_threshold(scarlet, images, centers, iters):
         close = rel_err(gm, o32[t]) <= TOL
         if mismatch.any():
             scale = np.abs(o64[t]).max()
-            on_threshold = np.abs(pre64[t][mismatch]) <= TOL * scale
+            near = np.minimum(np.abs(pre64[t][0][mismatch]), np.abs(pre64[t][1][mismatch]))
+            on_threshold = near <= TOL * scale
             if on_threshold.any():
                 k, y, x = (int(v[np.argmax(on_threshold)]) for v in np.nonzero(mismatch))
-                return True, ("iteration %d, component %d pixel (%d, %d): float64 value before prox_plus %.3e "
-                              "(|.| <= 1e-5 x %.3g), gpu %.3e, float32 oracle %.3e" % (
-                                  t + 1, k, y, x, pre64[t][k, y, x], scale, gm[k, y, x], o32[t][k, y, x]))
+                return True, ("iteration %d, component %d pixel (%d, %d): float64 values at the threshold tests: stepped "
+                              "%.3e, before prox_plus %.3e (tolerance 1e-5 x %.3g); gpu %.3e, float32 oracle %.3e" % (
+                                  t + 1, k, y, x, pre64[t][0][k, y, x], pre64[t][1][k, y, x], scale, gm[k, y, x],
+                                  o32[t][k, y, x]))
         if not close:
             return False, "iteration %d: gpu and float32 oracle differ by %.2e with no pixel on the prox_plus threshold" % (
                 t + 1, rel_err(gm, o32[t]))
