@@ -27,7 +27,7 @@ class BlendBatch(object):
     ----------
     images : (S, B, H, W) array or tensor
     centers : (S, K, 2) integer pixel centres (y, x) of the sources
-    weights : None (scalar 1, reference observation.py:148-151) or (S, B, H, W)
+    weights : None (scalar 1, reference observation.py:148-151), a Python scalar, or (S, B, H, W)
     symmetric, monotonic : constraint switches of PointSource/ExtendedSource.update
     l0_thresh, l1_thresh : None or sparsity thresholds (update.sparse_l0 / sparse_l1)
     centroid_weight : (P, P) float64 centroid PSF; default = reference default
@@ -49,6 +49,10 @@ class BlendBatch(object):
         assert self.centers.ndim == 3 and self.centers.shape[0] == S and self.centers.shape[2] == 2
         K = self.centers.shape[1]
         self.S, self.K, self.B, self.H, self.W = S, K, B, H, W
+        self._check_centers(self.centers)
+        self.weight_scalar = 1.0
+        if weights is not None and np.ndim(weights) == 0 and not torch.is_tensor(weights):
+            self.weight_scalar, weights = float(weights), None
         self.weights = None if weights is None else torch.as_tensor(weights).to(**f32).contiguous()
         self.sed = [torch.zeros((S, K, B), **f32) for _ in range(2)]
         self.morph = [torch.zeros((S, K, H, W), **f32) for _ in range(2)]
@@ -75,10 +79,20 @@ class BlendBatch(object):
         self._c.workspace = self.workspace.data_ptr()
 
     # ------------------------------------------------------------------ plumbing
+    def _check_centers(self, centers):
+        """Source centres index the frame directly (init, max_pixel window, sweeps): the reference raises
+        IndexError for a source outside the image; here it is a ValueError before anything is launched."""
+        c = centers
+        bad = (c[..., 0] < 0) | (c[..., 0] >= self.H) | (c[..., 1] < 0) | (c[..., 1] >= self.W)
+        if bool(bad.any().item()):
+            s, k = [int(v[0]) for v in self.torch.nonzero(bad, as_tuple=True)]
+            raise ValueError("centre %s of scene %d, source %d lies outside the %d x %d frame"
+                             % (tuple(int(v) for v in c[s, k].tolist()), s, k, self.H, self.W))
+
     def _fill_struct(self):
         c, p = self._c, (lambda t: None if t is None else t.data_ptr())
         c.S, c.K, c.B, c.H, c.W = self.S, self.K, self.B, self.H, self.W
-        c.images, c.weights, c.weight_scalar = p(self.images), p(self.weights), 1.0
+        c.images, c.weights, c.weight_scalar = p(self.images), p(self.weights), float(self.weight_scalar)
         c.sed[0], c.sed[1] = p(self.sed[0]), p(self.sed[1])
         c.morph[0], c.morph[1] = p(self.morph[0]), p(self.morph[1])
         c.cur = p(self.cur)
@@ -119,7 +133,9 @@ class BlendBatch(object):
             self.sed[b].copy_(sed)
             self.morph[b].copy_(morph)
         if centers is not None:
-            self.centers.copy_(t.as_tensor(np.asarray(centers)).to(self.centers))
+            new = t.as_tensor(np.asarray(centers)).to(self.centers)
+            self._check_centers(new)
+            self.centers.copy_(new)
         if shifts is not None:
             self.shifts.copy_(t.as_tensor(np.asarray(shifts, dtype=np.float64)).to(self.shifts))
 

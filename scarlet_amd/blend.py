@@ -97,7 +97,8 @@ class Blend(ComponentTree):
                             centroid_weight=cw)
             if images is None:
                 if type(o.weights) is not np.ndarray and o.weights != 1:
-                    ob._c.weight_scalar = float(o.weights)
+                    ob.weight_scalar = float(o.weights)
+                    ob._fill_struct()
                 if o._diff_kernels is not None:
                     ob.set_diff_kernel(np.asarray(o._diff_kernels.image, dtype=np.float32))
             return ob

@@ -441,6 +441,196 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_fft_convolve(const float *in, Fft
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused passes of the iteration kernel.  Neighbouring passes that touch the SAME set of positions per
+// thread are merged, so the data makes the LDS round trip once instead of two or three times:
+//   cols_A_untangle     : untangle of the real-row pairs (k, M-k) + column pass A on both columns
+//   cols_B_mul_Binv     : column pass B, * (conj) K-hat, inverse pass B^-1  (same R2y positions)
+//   cols_Ainv_tangle    : inverse column pass A^-1 on both columns + re-tangling of the pair
+//   rows_Ainv_resid_A   : last inverse row pass -> pixels in registers -> residual/loss -> first
+//                         forward row pass of the adjoint convolution        (same R1x positions)
+//   rows_Ainv_store     : last inverse row pass of the adjoint -> G in global memory
+// 14 passes (= barriers) per plane and iteration instead of 25.  Rows >= H of the plane are never
+// read from LDS (they are zero by construction: predicated), so nothing has to clear them.
+template <int R>
+__device__ __forceinline__ void cols_A_untangle(const FftLds &l, const FftPlan &p)
+{
+    const int M = p.M, NP = M / 2 + 1, R2 = p.R2y, RS = p.RS, H = p.H;
+    const int total = NP * R2;
+    const float rcp = 1.0f / (float)NP;
+    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+        const int n2 = fast_div(u, rcp), k = u - n2 * NP;
+        const bool first = (k == 0), mid = (2 * k == M);
+        const int ra = l.posx[k], rb = (first || mid) ? ra : l.posx[M - k];
+        const int cb = first ? M : rb;
+        const float2 w = l.twx[k];
+        float2 xa[R], xb[R];
+#pragma unroll
+        for (int n1 = 0; n1 < R; ++n1) {
+            const int r = R2 * n1 + n2;
+            float2 a = make_float2(0.f, 0.f), b = a;
+            if (r < H) { a = l.A[r * RS + ra]; b = l.A[r * RS + rb]; }
+            const float2 sm = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+            const float2 df = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+            const float2 wd = cmul(w, df);
+            xa[n1] = make_float2(sm.x + wd.y, sm.y - wd.x);
+            xb[n1] = make_float2(sm.x - wd.y, -sm.y - wd.x);
+        }
+        Dft<R, false>::run(xa);
+        Dft<R, false>::run(xb);
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) {
+            float2 va = xa[k1], vb = xb[k1];
+            if (k1 > 0) { const float2 t = l.twy[n2 * k1]; va = cmul(va, t); vb = cmul(vb, t); }
+            float2 *q = l.A + (R2 * k1 + n2) * RS;
+            q[ra] = va;
+            q[cb] = vb;               // k == M/2: the same value at the same place
+        }
+    }
+    __syncthreads();
+}
+
+template <int R, bool CONJ>
+__device__ __forceinline__ void cols_B_mul_Binv(const FftLds &l, const FftPlan &p, const float2 *khat)
+{
+    const int cols = p.M + 1, J = p.R1y, RS = p.RS;
+    const int total = cols * J;
+    const float rcp = 1.0f / (float)cols;
+    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+        const int k1 = fast_div(u, rcp), c = u - k1 * cols;
+        float2 *q = l.A + (R * k1) * RS + c;
+        const float2 *kq = khat + (R * k1) * cols + c;
+        float2 v[R], kk[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) kk[r] = kq[r * cols];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = q[r * RS];
+        Dft<R, false>::run(v);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = CONJ ? cmul_conj(v[r], kk[r]) : cmul(v[r], kk[r]);
+        Dft<R, true>::run(v);
+#pragma unroll
+        for (int r = 1; r < R; ++r) v[r] = cmul_conj(v[r], l.twy[r * k1]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r * RS] = v[r];
+    }
+    __syncthreads();
+}
+
+template <int R>
+__device__ __forceinline__ void cols_Ainv_tangle(const FftLds &l, const FftPlan &p)
+{
+    const int M = p.M, NP = M / 2 + 1, R2 = p.R2y, RS = p.RS, H = p.H;
+    const int total = NP * R2;
+    const float rcp = 1.0f / (float)NP;
+    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+        const int n2 = fast_div(u, rcp), k = u - n2 * NP;
+        const bool first = (k == 0), mid = (2 * k == M);
+        const int ra = l.posx[k], rb = (first || mid) ? ra : l.posx[M - k];
+        const int cb = first ? M : rb;
+        const float2 w = l.twx[k];
+        float2 xa[R], xb[R];
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) {
+            const float2 *q = l.A + (R2 * k1 + n2) * RS;
+            xa[k1] = q[ra];
+            xb[k1] = q[cb];
+        }
+        Dft<R, true>::run(xa);
+        Dft<R, true>::run(xb);
+#pragma unroll
+        for (int n1 = 0; n1 < R; ++n1) {
+            const int r = R2 * n1 + n2;
+            if (r < H) {
+                float2 xk = xa[n1], xm = xb[n1];
+                if (first) { xk.y = 0.f; xm.y = 0.f; }             // X[0], X[M] of a real signal are real
+                const float2 E = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+                const float2 D = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+                const float2 O = cmul_conj(D, w);
+                const float2 zk = make_float2(E.x - O.y, E.y + O.x);
+                const float2 zm = make_float2(E.x + O.y, -E.y + O.x);
+                l.A[r * RS + rb] = zm;                             // k == 0, M/2: same place as zk, written first
+                l.A[r * RS + ra] = zk;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// RESID: pixels -> d = w (render - image), loss, w d -> forward pass A of the adjoint convolution
+// !RESID: pixels -> G (global, compact)
+template <int R, bool RESID>
+__device__ __forceinline__ void rows_Ainv_final(const FftLds &l, const FftPlan &p, const float2 *img, const float2 *wgt,
+                                                float wscalar, float2 *gout, double &loss)
+{
+    const int R2 = p.R2x, RS = p.RS, H = p.H, Wh = p.W >> 1;
+    const int total = H * R2;
+    const float rcp = 1.0f / (float)R2;
+    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+        const int y = fast_div(u, rcp), n2 = u - y * R2;
+        float2 *q = l.A + y * RS + n2;
+        float2 v[R];
+        float2 im[R], ww[R];
+        if (RESID) {
+#pragma unroll
+            for (int n1 = 0; n1 < R; ++n1) {
+                const int n = R2 * n1 + n2;
+                im[n1] = make_float2(0.f, 0.f); ww[n1] = make_float2(0.f, 0.f);
+                if (n < Wh) {
+                    im[n1] = img[y * Wh + n];
+                    ww[n1] = wgt ? wgt[y * Wh + n] : make_float2(wscalar, wscalar);
+                }
+            }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) v[k1] = q[R2 * k1];
+        Dft<R, true>::run(v);
+        if (RESID) {
+#pragma unroll
+            for (int n1 = 0; n1 < R; ++n1) {
+                // outside the image ww = 0: the adjoint's input is zero there
+                const float dx = ww[n1].x * (v[n1].x - im[n1].x), dy = ww[n1].y * (v[n1].y - im[n1].y);
+                loss += (double)dx * (double)dx + (double)dy * (double)dy;
+                v[n1] = make_float2(ww[n1].x * dx, ww[n1].y * dy);
+            }
+            Dft<R, false>::run(v);
+#pragma unroll
+            for (int k1 = 1; k1 < R; ++k1) v[k1] = cmul(v[k1], l.twm[n2 * k1]);
+#pragma unroll
+            for (int k1 = 0; k1 < R; ++k1) q[R2 * k1] = v[k1];
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < R; ++n1) {
+                const int n = R2 * n1 + n2;
+                if (n < Wh) gout[y * Wh + n] = v[n1];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+#define SC_FFT_DISPATCH(R_, CALL)                                                                                  \
+    switch (R_) {                                                                                                  \
+    case 4: { constexpr int RR = 4; CALL; } break;    case 5: { constexpr int RR = 5; CALL; } break;               \
+    case 6: { constexpr int RR = 6; CALL; } break;    case 7: { constexpr int RR = 7; CALL; } break;               \
+    case 8: { constexpr int RR = 8; CALL; } break;    case 9: { constexpr int RR = 9; CALL; } break;               \
+    case 10: { constexpr int RR = 10; CALL; } break;  case 12: { constexpr int RR = 12; CALL; } break;             \
+    case 14: { constexpr int RR = 14; CALL; } break;  case 15: { constexpr int RR = 15; CALL; } break;             \
+    case 16: { constexpr int RR = 16; CALL; } break;  default: break;                                              \
+    }
+
+// one convolution up to (not including) the last inverse row pass: rows fwd, columns (fused), rows B^-1
+template <bool CONJ>
+__device__ __forceinline__ void fft_conv_core(const FftLds &l, const FftPlan &p, const float2 *khat, bool rows_A_done)
+{
+    if (!rows_A_done) fft_pass<false>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, true, false);      // rows A
+    fft_pass<false>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, false, false);                        // rows B
+    SC_FFT_DISPATCH(p.R1y, (cols_A_untangle<RR>(l, p)))
+    SC_FFT_DISPATCH(p.R2y, (cols_B_mul_Binv<RR, CONJ>(l, p, khat)))
+    SC_FFT_DISPATCH(p.R1y, (cols_Ainv_tangle<RR>(l, p)))
+    fft_pass<true>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, true, false);                          // rows B^-1
+}
+
 // the iteration's convolution pair: G_b = render^T( w^2 (render(model)_b - image_b) ), loss_b
 // grid: one workgroup per (scene, band), XCD-aware: the B planes of a scene share an XCD (their morphology
 // reads meet in that XCD's L2), consecutive scenes go to consecutive XCDs.
@@ -458,12 +648,12 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, fl
     const int c0 = a.cur[s];
     for (int k = threadIdx.x; k < K; k += SC_FFT_NT) sed_s[k] = a.sed[c0][((size_t)s * K + k) * B + b];
     __syncthreads();
-    // model_b into rows < H (pairs of pixels), zeros elsewhere
+    // model_b into rows < H (pairs of pixels), zeros up to column M
     const float *mor = a.morph[c0] + (size_t)s * K * HW;
-    for (int u = threadIdx.x; u < p.Fy * p.RS; u += SC_FFT_NT) {
-        const int y = u / p.RS, n = u - y * p.RS;
+    for (int u = threadIdx.x; u < H * M; u += SC_FFT_NT) {
+        const int y = u / M, n = u - y * M;
         float2 v = make_float2(0.f, 0.f);
-        if (y < H && n < Wh) {
+        if (n < Wh) {
             const float2 *mp = (const float2 *)(mor + y * W) + n;
             for (int k = 0; k < K; ++k) {
                 const float2 m = mp[(size_t)k * (HW / 2)];
@@ -471,39 +661,19 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, fl
                 v.x += sk * m.x; v.y += sk * m.y;
             }
         }
-        l.A[u] = v;
+        l.A[y * p.RS + n] = v;
     }
     __syncthreads();
     const float2 *khat = a.khat + (size_t)(a.khat_per_scene ? s * B + b : b) * p.Fy * (M + 1);
-    fft2d_fwd(l, p, H);
-    fft_spec_mul<false>(l, p, khat);
-    fft2d_inv(l, p, H);
-    // residual: d = w (render - image); loss; w d back into the plane, zeros around it
     const size_t plane = (size_t)s * B + b;
     const float2 *img = (const float2 *)(a.images + plane * HW);
     const float2 *wgt = a.weights ? (const float2 *)(a.weights + plane * HW) : nullptr;
-    double loss = 0;
-    for (int u = threadIdx.x; u < p.Fy * p.RS; u += SC_FFT_NT) {
-        const int y = u / p.RS, n = u - y * p.RS;
-        float2 v = make_float2(0.f, 0.f);
-        if (y < H && n < Wh) {
-            const float2 r = l.A[u], im = img[y * Wh + n];
-            const float2 w = wgt ? wgt[y * Wh + n] : make_float2(a.weight_scalar, a.weight_scalar);
-            const float dx = w.x * (r.x - im.x), dy = w.y * (r.y - im.y);
-            loss += (double)dx * (double)dx + (double)dy * (double)dy;
-            v = make_float2(w.x * dx, w.y * dy);
-        }
-        l.A[u] = v;
-    }
-    __syncthreads();
-    fft2d_fwd(l, p, H);
-    fft_spec_mul<true>(l, p, khat);
-    fft2d_inv(l, p, H);
     float2 *gp = (float2 *)(G + plane * HW);
-    for (int u = threadIdx.x; u < H * Wh; u += SC_FFT_NT) {
-        const int y = u / Wh, n = u - y * Wh;
-        gp[u] = l.A[y * p.RS + n];
-    }
+    double loss = 0;
+    fft_conv_core<false>(l, p, khat, false);
+    SC_FFT_DISPATCH(p.R1x, (rows_Ainv_final<RR, true>(l, p, img, wgt, a.weight_scalar, gp, loss)))
+    fft_conv_core<true>(l, p, khat, true);
+    SC_FFT_DISPATCH(p.R1x, (rows_Ainv_final<RR, false>(l, p, img, wgt, a.weight_scalar, gp, loss)))
     // loss of the plane
     loss = wave_sum(loss);
     if ((threadIdx.x & (SC_WAVE - 1)) == 0) red[threadIdx.x / SC_WAVE] = loss;

@@ -33,7 +33,12 @@ __device__ inline void max_pixel_tile(const Tile &t, int cy, int cx, int *out, i
 {
     if (threadIdx.x == 0) {
         int by = cy, bx = cx;
-        if (cy - 2 < 0 || cx - 2 < 0) {
+        if (cy >= t.H || cx >= t.W || cy < 0 || cx < 0) {
+            // a centre outside the frame (never produced by the engine; a caller's bad input): flagged and
+            // pulled onto the frame so that nothing downstream indexes outside the tile
+            *status_bits |= SCARLET_STATUS_CENTER_AT_EDGE;
+            by = min(max(cy, 0), t.H - 1); bx = min(max(cx, 0), t.W - 1);
+        } else if (cy - 2 < 0 || cx - 2 < 0) {
             *status_bits |= SCARLET_STATUS_CENTER_AT_EDGE;
         } else {
             const int y1 = min(cy + 3, t.H), x1 = min(cx + 3, t.W);

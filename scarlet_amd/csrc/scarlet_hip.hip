@@ -171,6 +171,11 @@ __global__ __launch_bounds__(SC_BLOCK) void k_operator(OpArgs a, float *gscratch
     if (threadIdx.x == 0) stat = 0;
     __syncthreads();
     const int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
+    if (cy < 0 || cy >= H || cx < 0 || cx >= W) {
+        // a centre outside the array (the reference raises IndexError): leave the array alone, flag it
+        if (threadIdx.x == 0 && a.status) atomicOr(&a.status[c], SCARLET_STATUS_CENTER_AT_EDGE);
+        return;
+    }
     bool writeback = !GT;
     switch (a.op) {
     case OP_MONO_WEIGHTED: monotonic_tile<false, float>(t, cy, cx, a.thresh); break;
@@ -218,6 +223,10 @@ __global__ __launch_bounds__(SC_BLOCK) void k_operator_w(OpArgs a)
     int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
     int stat = 0;
     bool writeback = true;
+    if (cy < 0 || cy >= H || cx < 0 || cx >= W) {         // as in k_operator
+        if (lane == 0 && a.status) atomicOr(&a.status[c], SCARLET_STATUS_CENTER_AT_EDGE);
+        return;
+    }
     switch (a.op) {
     case OP_MONO_WEIGHTED: wave_monotonic<float>(t, cy, cx, a.thresh); break;
     case OP_SYMMETRY: {
@@ -1366,6 +1375,7 @@ struct InitArgs {
     const int *cur;
     const int *centers;
     int *flags;
+    int *status;
     double bg_rms[SC_BMAX];
     double sed_scale[SC_BMAX];
     int has_scale;
@@ -1385,6 +1395,18 @@ __global__ __launch_bounds__(SC_BLOCK) void k_init_extended(InitArgs a, double *
     __shared__ double red[SC_NWAVES];
     __shared__ float sed_s[SC_BMAX];
     const int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
+    if (cy < 0 || cy >= H || cx < 0 || cx >= W) {
+        // a source outside the frame (IndexError in the reference, ValueError in BlendBatch): empty component
+        const int wb = a.cur[s];
+        float *gm0 = a.morph[wb] + (size_t)c * HW;
+        for (int i = threadIdx.x; i < HW; i += SC_BLOCK) gm0[i] = 0.f;
+        if (threadIdx.x < B) a.sed[wb][(size_t)c * B + threadIdx.x] = 0.f;
+        if (threadIdx.x == 0) {
+            a.flags[c] = SCARLET_FLAG_SED_NOT_CONVERGED | SCARLET_FLAG_MORPH_NOT_CONVERGED | SCARLET_FLAG_NO_VALID_PIXELS;
+            atomicOr(&a.status[s], SCARLET_STATUS_CENTER_AT_EDGE);
+        }
+        return;
+    }
     const float *img = a.images + (size_t)s * B * HW;
     // get_psf_sed (source.py:41-71): float32 like the reference (images.dtype)
     if (threadIdx.x < B) {
@@ -1468,6 +1490,7 @@ extern "C" int scarlet_init_extended(scarlet_batch *b, const float *bg_rms_host,
     a.S = b->S; a.K = b->K; a.B = b->B; a.H = b->H; a.W = b->W;
     a.images = b->images; a.sed[0] = b->sed[0]; a.sed[1] = b->sed[1];
     a.morph[0] = b->morph[0]; a.morph[1] = b->morph[1]; a.cur = b->cur; a.centers = b->centers; a.flags = b->flags;
+    a.status = b->status;
     a.has_scale = sed_scale_host != nullptr; a.thresh = thresh;
     a.do_symmetric = init_symmetric; a.do_monotonic = init_monotonic;
     a.no_hybrid = opt(OPT_NO_HYBRID_SWEEP) ? 1 : 0;

@@ -43,7 +43,13 @@ __device__ __forceinline__ void key_max_step(unsigned &hi, unsigned &lo)
 }
 __device__ inline void wave_max_pixel(const Tile &t, int &cy, int &cx, int &status_bits)
 {
-    if (cy - 2 < 0 || cx - 2 < 0) { status_bits |= SCARLET_STATUS_CENTER_AT_EDGE; return; }
+    if (cy - 2 < 0 || cx - 2 < 0 || cy >= t.H || cx >= t.W) {
+        // low edge: the reference fails (centre kept); a centre outside the frame (a caller's bad input) is
+        // pulled onto the frame so that nothing downstream indexes outside the tile
+        status_bits |= SCARLET_STATUS_CENTER_AT_EDGE;
+        cy = min(max(cy, 0), t.H - 1); cx = min(max(cx, 0), t.W - 1);
+        return;
+    }
     const int lane = lane_id();
     const int wy = lane / 5, wx = lane - wy * 5;
     const int y = cy - 2 + wy, x = cx - 2 + wx;

@@ -11,7 +11,9 @@ import numpy as np
 def load_scene(path):
     """Read one scene file.  Returns a dict with
     images (B,H,W) float32, psfs (B,P,P) float32 or None, weights (B,H,W) float32 or None
-    (inverse variance, zero where masked), channels (list of str) or None,
+    (1 / sqrt(variance), zero where masked or variance <= 0: `weights` MULTIPLIES the residual in
+    Observation.get_loss -- 0.5 sum (w (model - image))^2, reference observation.py:239 -- so this
+    is the inverse-variance chi-square), channels (list of str) or None,
     centers (K,2) int32 -- catalog positions rounded to pixels, (y, x) order."""
     with np.load(path, allow_pickle=False) as d:
         files = set(d.files)
@@ -20,7 +22,7 @@ def load_scene(path):
         weights = None
         if "variance" in files:
             var = np.asarray(d["variance"], dtype=np.float32)
-            weights = np.where(var > 0, 1.0 / np.where(var > 0, var, 1), 0).astype(np.float32)
+            weights = np.where(var > 0, 1.0 / np.sqrt(np.where(var > 0, var, 1)), 0).astype(np.float32)
         if "mask" in files:
             good = np.asarray(d["mask"]) == 0
             weights = good.astype(np.float32) if weights is None else weights * good
@@ -33,6 +35,10 @@ def load_scene(path):
         else:
             yx = np.zeros((0, 2))
     centers = np.rint(yx).astype(np.int32)
+    H, W = images.shape[-2:]
+    if len(centers) and ((centers[:, 0] < 0) | (centers[:, 0] >= H) | (centers[:, 1] < 0) | (centers[:, 1] >= W)).any():
+        raise ValueError("catalog position outside the %d x %d frame in %s (the reference raises IndexError "
+                         "when a source is initialised there)" % (H, W, path))
     return dict(images=images, psfs=psfs, weights=weights, channels=channels, centers=centers)
 
 

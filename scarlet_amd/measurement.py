@@ -5,7 +5,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .operator import _OnDevice, _i32
+from .operator import _OnDevice, _i32, _i32_center
 
 
 def max_pixel(morph, center=None, window=None):
@@ -43,10 +43,10 @@ def psf_weighted_centroid(morph, psf, pixel_center):
     assert p.ndim == 2 and p.shape[0] == p.shape[1] and p.shape[0] % 2 == 1, "psf must be square and odd"
     pd = torch.as_tensor(np.ascontiguousarray(p, dtype=np.float64)).cuda()
     with _OnDevice(morph) as t:
-        c = _i32(pixel_center)
+        H, W = t.shape
+        c = _i32_center(pixel_center, H, W)
         sh = torch.zeros((1, 2), dtype=torch.float64, device="cuda")
         st = torch.zeros(1, dtype=torch.int32, device="cuda")
-        H, W = t.shape
         _lib.check(_lib.lib.scarlet_psf_weighted_centroid(_lib.ptr(t), 1, H, W, _lib.ptr(pd), p.shape[0],
                                                           _lib.ptr(c), _lib.ptr(sh), _lib.ptr(st), _lib.stream_ptr()))
         cen, shift = c.cpu().numpy()[0], sh.cpu().numpy()[0]

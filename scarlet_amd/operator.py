@@ -48,6 +48,14 @@ def _i32(pairs):
     return torch.as_tensor(np.asarray(pairs, dtype=np.int32).reshape(-1, 2)).cuda().contiguous()
 
 
+def _i32_center(pairs, H, W):
+    """Centres that index an H x W array (the reference raises IndexError outside it)."""
+    a = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    if ((a[:, 0] < 0) | (a[:, 0] >= H) | (a[:, 1] < 0) | (a[:, 1] >= W)).any():
+        raise IndexError("center %s is outside the %d x %d array" % (a.tolist(), H, W))
+    return _i32(a)
+
+
 def _f64(pairs):
     torch = _lib.require_gpu()
     return torch.as_tensor(np.asarray(pairs, dtype=np.float64).reshape(-1, 2)).cuda().contiguous()
@@ -80,8 +88,8 @@ def _prox_weighted_monotonic(X, step, center, thresh=0):
     """operators_pybind11.prox_weighted_monotonic with the weights and the radial order
     generated on the device from `center` (reference operator.py:32-37, 540-621)."""
     with _OnDevice(X) as t:
-        c = _i32(center)
         H, W = t.shape[-2:]
+        c = _i32_center(center, H, W)
         _lib.check(_lib.lib.scarlet_prox_weighted_monotonic(_lib.ptr(t), 1, H, W, _lib.ptr(c),
                                                             ctypes.c_float(thresh), _lib.stream_ptr()))
     return X
@@ -91,8 +99,8 @@ def _prox_strict_monotonic(X, step, center, thresh=0):
     """operators_pybind11.prox_monotonic: nearest-neighbour reference pixel
     (reference operator.py:24-29)."""
     with _OnDevice(X) as t:
-        c = _i32(center)
         H, W = t.shape[-2:]
+        c = _i32_center(center, H, W)
         _lib.check(_lib.lib.scarlet_prox_nearest_monotonic(_lib.ptr(t), 1, H, W, _lib.ptr(c),
                                                            ctypes.c_float(thresh), _lib.stream_ptr()))
     return X
@@ -119,7 +127,7 @@ def prox_strict_monotonic(shape, use_nearest=False, thresh=0, center=None):
 def _symmetry(X, center, algorithm, strength, fill, shift, full=False):
     with _OnDevice(X) as t:
         H, W = t.shape
-        c = _i32((0, 0) if center is None else center)
+        c = _i32_center((0, 0) if center is None else center, H, W)
         sh = None if shift is None else _f64(shift)
         alg = _ALG[algorithm] | (_lib.SYM_FULL_WINDOW if full else 0)
         _lib.check(_lib.lib.scarlet_prox_symmetry(

@@ -67,3 +67,31 @@ def test_no_cpu_fallback_without_gpu():
         sc.BlendBatch(np.zeros((1, 5, 16, 16), np.float32), np.zeros((1, 1, 2), np.int32) + 8)
     with pytest.raises(RuntimeError):
         sc.operator.prox_soft_symmetry(np.zeros((5, 5), np.float32), 0)
+
+
+def test_error_paths_return_codes_without_touching_memory():
+    """argument errors come back as SCARLET_E_ARG with a message, before anything is allocated or launched"""
+    import numpy as np
+    from scarlet_amd import _lib
+    x = np.zeros(30, np.float32)
+    rc = _lib.lib.scarlet_host_prox_weighted_monotonic_f32(None, 30, x.ctypes.data, x.ctypes.data, x.ctypes.data, 29, 0.0)
+    assert rc == _lib.E_ARG and _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+    assert _lib.lib.scarlet_set_option(b"NO_SUCH_OPTION", 1) == _lib.E_ARG
+    assert _lib.set_option("NO_FUSED", 1) == 0 and _lib.set_option("NO_FUSED", 0) == 1
+    assert _lib.lib.scarlet_fit(None, 1, 0.0, 0, 0, None) == _lib.E_ARG
+    assert _lib.lib.scarlet_batch_workspace_bytes(None) == 0
+
+
+def test_asan_error_paths():
+    """`make asan`: the host code of the library under AddressSanitizer + LeakSanitizer, driven through the
+    argument-error and HIP-error exits of every entry point that allocates (tests/native/abi_asan_check.c).
+    Without a GPU every hipMalloc fails, which is exactly the set of early returns that must not leak."""
+    csrc = os.path.join(ROOT, "scarlet_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "asan"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "tests", "native", "_build", "abi_asan_check")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:exitcode=23")
+    out = subprocess.run([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    assert b"abi_asan_check ok" in out.stdout

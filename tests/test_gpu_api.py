@@ -541,3 +541,99 @@ def test_combined_extended_source_matches_the_reference(scarlet):
     assert rel_err(np.array([npy(c.morph) for c in blend.components]), g["morph"]) < 1e-5
     assert rel_err(np.array([npy(c.sed) for c in blend.components]), g["sed"]) < 1e-5
     assert_array_equal(np.array([c.pixel_center for c in blend.components]), g["center"])
+
+
+# ---------------------------------------------------------------------------------------------
+# robustness of the boundary: centres outside the frame, scalar weights, threads
+def test_centre_outside_the_frame_is_rejected(scarlet):
+    """the reference raises IndexError for a source outside the image; BlendBatch raises ValueError before
+    any launch, io.load_scene refuses the catalogue, and the C ABI itself (a caller that skipped the host
+    check) flags the scene instead of reading outside the frame"""
+    from scarlet_amd import synth, _lib
+    import ctypes
+    d = synth.make_batch(77, 3)
+    bad = d["centers"].copy()
+    bad[1, 2] = (64, 10)                                   # y == H: what np.rint of a catalogue can produce
+    with pytest.raises(ValueError):
+        scarlet.BlendBatch(d["images"], bad)
+    b = scarlet.BlendBatch(d["images"], d["centers"])
+    with pytest.raises(ValueError):
+        b.set_state(np.zeros((3, 4, 5)), np.zeros((3, 4, 64, 64)), centers=bad)
+    with pytest.raises(IndexError):
+        scarlet.operator.prox_strict_monotonic((9, 9), center=(9, 4))(np.ones((9, 9), np.float32), 0)
+    # straight through the C ABI: overwrite the device centres behind the host check
+    b.centers.copy_(torch.as_tensor(bad).to(b.centers))
+    b.init_extended(np.ones(5) * 0.1)
+    b.fit(3, e_rel=0)
+    torch.cuda.synchronize()
+    st = b.status.cpu().numpy()
+    assert st[1] & _lib.STATUS_CENTER_AT_EDGE and st[0] == 0 and st[2] == 0
+    assert int(b.flags[1, 2].item()) & _lib.FLAG_NO_VALID_PIXELS
+    ok = scarlet.BlendBatch(d["images"], d["centers"]).init_extended(np.ones(5) * 0.1)
+    ok.fit(3, e_rel=0)
+    for s in (0, 2):                                       # the healthy scenes are untouched by their neighbour
+        np.testing.assert_array_equal(b.morph_current[s].cpu().numpy(), ok.morph_current[s].cpu().numpy())
+
+
+def test_scalar_weight_survives_struct_refills(scarlet):
+    """a Python-scalar weight != 1 (observation.py:148-151) is a batch attribute: fixed factors and a growing
+    loss history both rebuild the C struct and must keep it"""
+    from scarlet_amd import synth
+    from oracle import pgm
+    scn = synth.make_scene(4242)
+    w = 0.5
+    b = scarlet.BlendBatch(scn["images"][None], scn["centers"][None], weights=w, mse_capacity=4)
+    assert b.weights is None and b.weight_scalar == w
+    b.init_extended(np.ones(5) * 0.1)
+    st = [t.cpu().numpy()[0] for t in (b.sed_current, b.morph_current, b.centers, b.shifts)]
+    b.fix_sed = torch.zeros((1, 4), dtype=torch.uint8, device="cuda")
+    b.fix_sed[0, 1] = 1
+    b._fill_struct()
+    b.fit(3, e_rel=0)
+    b.fit(6, e_rel=0)                                      # grows the loss history: the struct is refilled again
+    torch.cuda.synchronize()
+    sc = pgm.scene_from_state(scn["images"], st[0], st[1], st[2], st[3], weights=w)
+    sc.sources[1].fix_sed = True
+    pgm.fit(sc, 9, e_rel=0)
+    assert rel_err(b.mse(0), sc.mse) < 1e-5
+    assert rel_err(b.morph_current[0].cpu().numpy(), np.array([s.morph for s in sc.sources])) < 1e-5
+    assert rel_err(b.sed_current[0].cpu().numpy(), np.array([s.sed for s in sc.sources])) < 1e-5
+
+
+def test_two_host_threads_on_two_streams(scarlet):
+    """include/scarlet_hip.h: entry points may be called from several host threads at once on different batches
+    and streams.  Two threads fit different batches concurrently (fused path and PSF path, which shares the
+    plan/option/profile globals); results equal the single-threaded runs bit for bit."""
+    import threading
+    from scarlet_amd import synth
+    d1, d2 = synth.make_batch(900, 64), synth.make_batch(1900, 8, H=48, W=40, K=3)
+    ker = np.zeros((5, 7, 7), np.float32); ker[:, 3, 3] = 0.6; ker[:, 3, 2] = ker[:, 2, 3] = ker[:, 3, 4] = ker[:, 4, 3] = 0.1
+    def run1(out, key):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            b = scarlet.BlendBatch(d1["images"], d1["centers"]).init_extended(np.ones(5) * 0.1)
+            for _ in range(4):
+                b.fit(5, e_rel=0, check_every=0)
+            torch.cuda.current_stream().synchronize()
+            out[key] = b.morph_current.cpu().numpy()
+    def run2(out, key):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            b = scarlet.BlendBatch(d2["images"], d2["centers"])
+            b.set_diff_kernel(ker)
+            b.init_extended(np.ones(5) * 0.1)
+            for _ in range(4):
+                b.fit(5, e_rel=0, check_every=0)
+            torch.cuda.current_stream().synchronize()
+            out[key] = b.morph_current.cpu().numpy()
+    ref = {}
+    run1(ref, "a"); run2(ref, "b")
+    got, errs = {}, []
+    def guarded(fn, key):
+        try:
+            fn(got, key)
+        except Exception as e:                              # surfaced below: a thread's exception is otherwise lost
+            errs.append(e)
+    th = [threading.Thread(target=guarded, args=(run1, "a")), threading.Thread(target=guarded, args=(run2, "b"))]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    np.testing.assert_array_equal(got["a"], ref["a"])
+    np.testing.assert_array_equal(got["b"], ref["b"])

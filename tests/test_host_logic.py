@@ -125,7 +125,7 @@ def test_scene_npz_loader(tmp_path):
     assert s["images"].dtype == np.float32 and s["psfs"].dtype == np.float32 and s["channels"] == list("griz")
     assert s["centers"].tolist() == [[7, 10], [9, 21], [30, 6]]          # (y, x), round half to even
     assert s["weights"][0, 0, 0] == 0 and s["weights"][1, 2, 3] == 0
-    np.testing.assert_allclose(s["weights"][2], 1 / var[2])
+    np.testing.assert_allclose(s["weights"][2], 1 / np.sqrt(var[2]), rtol=1e-6)
     images, centers, weights = io.stack_scenes([s, s])
     assert images.shape == (2, 4, 40, 32) and centers.shape == (2, 3, 2) and weights.shape == images.shape
     assert io.group_by_shape([s, s]) == {(4, 40, 32, 3): [0, 1]}
