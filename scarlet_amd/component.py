@@ -49,6 +49,19 @@ def _to_device(a, shape=None):
     return t.contiguous().clone()
 
 
+def _require_float32_frame(frame):
+    """The HIP engine stores and steps the factors in float32 (reductions -- loss, Gram matrices, moments,
+    convergence sums -- accumulate in float64).  A float64 MODEL frame (reference observation.py:29-54,
+    component.py:94-95 cast the factors to frame.dtype) would promise double-precision factors that this
+    engine does not compute, so it is refused instead of being silently down-cast.  float64 DATA is fine:
+    Observation.match casts images / weights / PSFs to the model frame's dtype, as the reference does
+    (observation.py:172-181)."""
+    if np.dtype(getattr(frame, "dtype", np.float32)) != np.dtype(np.float32):
+        raise TypeError("scarlet_amd computes in float32: a model Frame with dtype %s is not supported "
+                        "(build the Frame with dtype=numpy.float32; float64 images are cast by Observation.match)"
+                        % np.dtype(frame.dtype))
+
+
 class Component(object):
     """A single component of a blend: ``model = sed[:, None, None] * morph[None]``.
 
@@ -58,6 +71,7 @@ class Component(object):
 
     def __init__(self, frame, sed, morph, prior=None, fix_sed=False, fix_morph=False):
         self._frame = frame
+        _require_float32_frame(frame)
         self._own_sed = _to_device(sed)
         self._own_morph = _to_device(morph)
         self._binding = None            # (blend, k) once adopted by a Blend

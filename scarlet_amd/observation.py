@@ -3,8 +3,9 @@
 `Frame` describes the model (shape, PSF, channels, dtype); `Observation` holds the data
 (images, weights, PSFs) and, after ``match(model_frame)``, the band slice and the PSF
 difference kernel that map the model into the observed frame.  Data live on the device;
-the engine computes in float32 whatever `dtype` is requested (float64 frames are accepted
-for API compatibility and cast, with a warning).
+the engine computes in float32: a float64 DATA frame is cast to the model frame's dtype by ``match``
+(as in the reference), a float64 MODEL frame is refused when the first Component is built on it
+(component._require_float32_frame).
 """
 import logging
 

@@ -254,3 +254,17 @@ def test_project_image_reference_vectors():
         assert_array_equal(project_image(img, shape, yx0), truth)
     a, b = common_projections(np.ones((3, 7)), np.ones((5, 4)))
     assert a.shape == b.shape == (5, 7) and a.sum() == 21 and b.sum() == 20
+
+
+def test_float64_model_frame_is_refused_loudly():
+    """a float64 model Frame promised double-precision factors that the float32 engine does
+    not compute; it is refused (before anything touches the device) instead of silently down-cast.
+    float64 DATA stays fine: Observation builds a float64 data frame and match() casts it."""
+    import scarlet_amd as sc
+    frame64 = sc.Frame((3, 8, 8), psfs=None, dtype=np.float64)
+    with pytest.raises(TypeError, match="float32"):
+        sc.Component(frame64, np.ones(3), np.ones((8, 8)))
+    obs = sc.Observation(np.zeros((3, 8, 8), dtype=np.float64))
+    assert np.dtype(obs.frame.dtype) == np.float64
+    obs.match(sc.Frame((3, 8, 8), psfs=None, dtype=np.float32))
+    assert obs.images.dtype == np.float32
