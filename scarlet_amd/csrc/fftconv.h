@@ -198,7 +198,9 @@ template <int N, bool INV> struct Dft {
 
 // ------------------------------------------------------------------------------------------------
 // the plan: shapes, radices, placement; tables in device memory (built on the host in float64)
+#ifndef SC_FFT_NT
 #define SC_FFT_NT 512                   // threads of the convolution workgroup
+#endif
 #define SC_FFT_MAXF 256
 struct FftPlan {
     int H, W;                           // image
@@ -206,12 +208,23 @@ struct FftPlan {
     int R1y, R2y, R1x, R2x;             // Fy = R1y R2y, M = R1x R2x
     int Py, Px, oky, okx;               // kernel shape and its offsets inside the periodic plane
     float scale;                        // 1 / (M Fy): the two unnormalised inverse transforms
+    int stagger_wgs;                    // k_psf_conv: number of workgroups of the first generation (CUs of the device)
+    int tab_off;                        // LDS offset (float2) of the tables: behind the plane and the image staging area
+    int dma_image;                      // k_psf_conv: the image is staged in LDS by LDS-DMA (rows >= H + the space behind the plane)
     const float2 *tables;               // device: twy[Fy] = w_Fy^j, twm[M] = w_M^j, twx[M/2 + 1] = w_Fx^k, then posx[M] (uint16)
 };
 __host__ __device__ inline int fft_table_float2s(int Fy, int M) { return Fy + M + (M / 2 + 1) + (M + 3) / 4; }
-__host__ __device__ inline size_t fft_lds_bytes(int Fy, int M, int RS)
+// LDS of the transform kernels: the plane [Fy][RS], then the tables.  k_psf_conv additionally stages the image
+// plane (H x W floats) from row H on -- rows >= H are idle between the render's column stage and the adjoint's,
+// which is when the residual needs the image -- so its tables sit behind max(plane, H rows + image).
+__host__ __device__ inline int fft_tab_off(int Fy, int RS, int H, int W, bool stage_image)
 {
-    return sizeof(float2) * ((size_t)Fy * RS + fft_table_float2s(Fy, M));
+    const int plane = Fy * RS, staged = H * RS + (H * W + 1) / 2;
+    return (stage_image && staged > plane) ? staged : plane;
+}
+__host__ __device__ inline size_t fft_lds_bytes(int Fy, int M, int RS, int H = 0, int W = 0, bool stage_image = false)
+{
+    return sizeof(float2) * ((size_t)fft_tab_off(Fy, RS, H, W, stage_image) + fft_table_float2s(Fy, M));
 }
 
 // exact u / d for 0 <= u < 2^20, 1 <= d < 2^12 (float reciprocal)
@@ -285,7 +298,7 @@ __device__ __forceinline__ FftLds fft_lds_setup(float2 *lds, const FftPlan &p)
 {
     FftLds l;
     l.A = lds;
-    float2 *t = lds + (size_t)p.Fy * p.RS;
+    float2 *t = lds + p.tab_off;
     const int nt = fft_table_float2s(p.Fy, p.M);
     for (int i = threadIdx.x; i < nt; i += SC_FFT_NT) t[i] = p.tables[i];
     l.twy = t; l.twm = t + p.Fy; l.twx = l.twm + p.M;
@@ -557,53 +570,46 @@ __device__ __forceinline__ void cols_Ainv_tangle(const FftLds &l, const FftPlan 
     __syncthreads();
 }
 
-// RESID: pixels -> d = w (render - image), loss, w d -> forward pass A of the adjoint convolution
-// !RESID: pixels -> G (global, compact)
-template <int R, bool RESID>
-__device__ __forceinline__ void rows_Ainv_final(const FftLds &l, const FftPlan &p, const float2 *img, const float2 *wgt,
-                                                float wscalar, float2 *gout, double &loss)
+// The image plane of the residual pass, global -> LDS by LDS-DMA (no registers: a register prefetch across the
+// render's passes is either sunk to its uses by the compiler -- sixteen exposed HBM round trips, measured --
+// or spills).  16 B per lane, wave-uniform LDS base + lane * 16: the staged image is lane-linear [H][W] floats.
+// Requested after the render's column stage, landed by the barrier that ends the next row pass.
+#define SC_FFT_PF 16                     // model-plane pairs a thread holds in registers at kernel start
+__device__ __forceinline__ void fft_dma_image(const FftLds &l, const FftPlan &p, const float *img)
 {
-    const int R2 = p.R2x, RS = p.RS, H = p.H, Wh = p.W >> 1;
-    const int total = H * R2;
-    const float rcp = 1.0f / (float)R2;
-    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
-        const int y = fast_div(u, rcp), n2 = u - y * R2;
-        float2 *q = l.A + y * RS + n2;
-        float2 v[R];
-        float2 im[R], ww[R];
-        if (RESID) {
-#pragma unroll
-            for (int n1 = 0; n1 < R; ++n1) {
-                const int n = R2 * n1 + n2;
-                im[n1] = make_float2(0.f, 0.f); ww[n1] = make_float2(0.f, 0.f);
-                if (n < Wh) {
-                    im[n1] = img[y * Wh + n];
-                    ww[n1] = wgt ? wgt[y * Wh + n] : make_float2(wscalar, wscalar);
-                }
-            }
-        }
-#pragma unroll
-        for (int k1 = 0; k1 < R; ++k1) v[k1] = q[R2 * k1];
-        Dft<R, true>::run(v);
-        if (RESID) {
-#pragma unroll
-            for (int n1 = 0; n1 < R; ++n1) {
-                // outside the image ww = 0: the adjoint's input is zero there
-                const float dx = ww[n1].x * (v[n1].x - im[n1].x), dy = ww[n1].y * (v[n1].y - im[n1].y);
-                loss += (double)dx * (double)dx + (double)dy * (double)dy;
-                v[n1] = make_float2(ww[n1].x * dx, ww[n1].y * dy);
-            }
-            Dft<R, false>::run(v);
-#pragma unroll
-            for (int k1 = 1; k1 < R; ++k1) v[k1] = cmul(v[k1], l.twm[n2 * k1]);
-#pragma unroll
-            for (int k1 = 0; k1 < R; ++k1) q[R2 * k1] = v[k1];
-        } else {
-#pragma unroll
-            for (int n1 = 0; n1 < R; ++n1) {
-                const int n = R2 * n1 + n2;
-                if (n < Wh) gout[y * Wh + n] = v[n1];
-            }
+    const int nchunks = (p.H * p.W) >> 2;             // 16-byte pieces (H W % 4 == 0: checked on the host)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *stage = reinterpret_cast<float *>(l.A + p.H * p.RS);
+    for (int c0 = wave * 64; c0 < nchunks; c0 += SC_FFT_NT) {
+        if (c0 + lane < nchunks)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (size_t)(c0 + lane) * 4),
+                                             (__attribute__((address_space(3))) void *)(stage + (size_t)c0 * 4), 16, 0, 0);
+    }
+}
+// d = w (render - image), loss, w d back into the plane (columns >= W/2 of the rows stay zero from the build);
+// `pf` holds the first SC_FFT_PF * SC_FFT_NT pairs, the rest (larger frames) is read here
+__device__ __forceinline__ void fft_residual(const FftLds &l, const FftPlan &p, const float2 *img,
+                                             const float2 *wgt, float wscalar, double &loss)
+{
+    const int Wh = p.W >> 1, npairs = p.H * Wh;
+    const float rcp = 1.0f / (float)Wh;
+    const float2 *stage = l.A + p.H * p.RS;           // the image as the LDS-DMA left it: [H][W/2] pairs, lane-linear
+    for (int u = threadIdx.x; u < npairs; u += SC_FFT_NT) {
+        const int y = fast_div(u, rcp), n = u - y * Wh;
+        float2 *q = l.A + y * p.RS + n;
+        const float2 r = *q, im = p.dma_image ? stage[u] : img[u];
+        const float2 w = wgt ? wgt[u] : make_float2(wscalar, wscalar);
+        const float dx = w.x * (r.x - im.x), dy = w.y * (r.y - im.y);
+        loss += (double)dx * (double)dx + (double)dy * (double)dy;
+        *q = make_float2(w.x * dx, w.y * dy);
+    }
+    // the inverse transform leaves (tiny) values in columns W/2 .. M-1 of the rows: the adjoint's input is zero there
+    const int pad = p.M - Wh;
+    if (pad > 0) {
+        const float rcp2 = 1.0f / (float)pad;
+        for (int u = threadIdx.x; u < p.H * pad; u += SC_FFT_NT) {
+            const int y = fast_div(u, rcp2), n = Wh + (u - y * pad);
+            l.A[y * p.RS + n] = make_float2(0.f, 0.f);
         }
     }
     __syncthreads();
@@ -620,60 +626,99 @@ __device__ __forceinline__ void rows_Ainv_final(const FftLds &l, const FftPlan &
     }
 
 // one convolution up to (not including) the last inverse row pass: rows fwd, columns (fused), rows B^-1
-template <bool CONJ>
-__device__ __forceinline__ void fft_conv_core(const FftLds &l, const FftPlan &p, const float2 *khat, bool rows_A_done)
+#define FFT_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+template <bool CONJ, typename AfterColumns>
+__device__ __forceinline__ void fft_conv_core(const FftLds &l, const FftPlan &p, const float2 *khat, long long *stamps,
+                                              AfterColumns &&after_columns)
 {
-    if (!rows_A_done) fft_pass<false>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, true, false);      // rows A
+    fft_pass<false>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, true, false);                         // rows A
+    FFT_STAMP(0);
     fft_pass<false>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, false, false);                        // rows B
+    FFT_STAMP(1);
     SC_FFT_DISPATCH(p.R1y, (cols_A_untangle<RR>(l, p)))
+    FFT_STAMP(2);
     SC_FFT_DISPATCH(p.R2y, (cols_B_mul_Binv<RR, CONJ>(l, p, khat)))
+    FFT_STAMP(3);
     SC_FFT_DISPATCH(p.R1y, (cols_Ainv_tangle<RR>(l, p)))
+    FFT_STAMP(4);
+    after_columns();                     // the low-register-pressure row passes follow: global loads go here
     fft_pass<true>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, true, false);                          // rows B^-1
+    FFT_STAMP(5);
+    fft_pass<true>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, false, false);                         // rows A^-1
+    FFT_STAMP(6);
 }
 
-// the iteration's convolution pair: G_b = render^T( w^2 (render(model)_b - image_b) ), loss_b
-// grid: one workgroup per (scene, band), XCD-aware: the B planes of a scene share an XCD (their morphology
-// reads meet in that XCD's L2), consecutive scenes go to consecutive XCDs.
-__global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, float *G)
+// the iteration's convolution pair: G_b = render^T( w^2 (render(model)_b - image_b) ), loss_b.
+// `G` holds the model planes model_b = sum_k sed[k][b] morph[k] on entry ([S][B][H][W], written by k_psf_model:
+// one streaming read of the K morphologies per SCENE -- building the plane here costs K plane reads per
+// BAND through this CU's load path, a third of the kernel when measured) and the gradient planes on exit.
+// grid: one workgroup per (scene, band); consecutive scenes go to consecutive XCDs.
+__global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, float *G, long long *stamps_all)
 {
     extern __shared__ __align__(16) float2 fft_lds[];
-    const int B = a.B, K = a.K;
+    const int B = a.B;
     const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
     const int grp = t / B, b = t - grp * B, s = grp * 8 + xcd;
     if (s >= a.S || !a.active[s]) return;
-    const FftLds l = fft_lds_setup(fft_lds, p);
-    __shared__ float sed_s[SC_KBIG];
-    __shared__ double red[SC_FFT_NT / SC_WAVE];
+    long long *stamps = stamps_all ? stamps_all + ((size_t)s * B + b) * 32 : nullptr;
+    // Every workgroup does the same work in the same time, one per CU: left alone, all CUs stay in lockstep and
+    // each global-memory phase (model plane, image, K-hat, G) hits HBM as one chip-wide burst, served at the
+    // chip's rate with every wave stalled at issue (measured: 6k cycles to issue 16 loads).  The first
+    // generation of workgroups is therefore spread over one plane time; the offsets persist because each CU
+    // runs its workgroups back to back.
+    if (blockIdx.x < (unsigned)p.stagger_wgs) {
+        const int slots = (int)((blockIdx.x * 2654435761u) >> 26);          // 0 .. 63, scrambled
+        for (int i = 0; i < slots; ++i) __builtin_amdgcn_s_sleep(32);       // 64 x ~2k cycles
+    }
+    FFT_STAMP(30);
     const int H = p.H, W = p.W, M = p.M, HW = H * W, Wh = W >> 1;           // W even (checked on the host)
-    const int c0 = a.cur[s];
-    for (int k = threadIdx.x; k < K; k += SC_FFT_NT) sed_s[k] = a.sed[c0][((size_t)s * K + k) * B + b];
-    __syncthreads();
-    // model_b into rows < H (pairs of pixels), zeros up to column M
-    const float *mor = a.morph[c0] + (size_t)s * K * HW;
-    for (int u = threadIdx.x; u < H * M; u += SC_FFT_NT) {
-        const int y = u / M, n = u - y * M;
-        float2 v = make_float2(0.f, 0.f);
-        if (n < Wh) {
-            const float2 *mp = (const float2 *)(mor + y * W) + n;
-            for (int k = 0; k < K; ++k) {
-                const float2 m = mp[(size_t)k * (HW / 2)];
-                const float sk = sed_s[k];
-                v.x += sk * m.x; v.y += sk * m.y;
-            }
+    const size_t plane = (size_t)s * B + b;
+    float2 *gp = (float2 *)(G + plane * HW);
+    const float2 *img = (const float2 *)(a.images + plane * HW);
+    const float2 *wgt = a.weights ? (const float2 *)(a.weights + plane * HW) : nullptr;
+    // model plane -> rows < H (pixel pairs), zeros up to column M
+    const FftLds l = fft_lds_setup(fft_lds, p);
+    float2 mreg[SC_FFT_PF];
+#pragma unroll
+    for (int j = 0; j < SC_FFT_PF; ++j) {
+        const int u = threadIdx.x + j * SC_FFT_NT;
+        mreg[j] = u < H * Wh ? gp[u] : make_float2(0.f, 0.f);
+    }
+    __shared__ double red[SC_FFT_NT / SC_WAVE];
+    {
+        const float rcp = 1.0f / (float)M;
+        for (int u = threadIdx.x; u < H * M; u += SC_FFT_NT) {
+            const int y = fast_div(u, rcp), n = u - y * M;
+            if (n >= Wh) l.A[y * p.RS + n] = make_float2(0.f, 0.f);
         }
-        l.A[y * p.RS + n] = v;
+        const float rcpw = 1.0f / (float)Wh;
+#pragma unroll
+        for (int j = 0; j < SC_FFT_PF; ++j) {
+            const int u = threadIdx.x + j * SC_FFT_NT;
+            if (u < H * Wh) { const int y = fast_div(u, rcpw), n = u - y * Wh; l.A[y * p.RS + n] = mreg[j]; }
+        }
+        for (int u = threadIdx.x + SC_FFT_PF * SC_FFT_NT; u < H * Wh; u += SC_FFT_NT) {
+            const int y = fast_div(u, rcpw), n = u - y * Wh;
+            l.A[y * p.RS + n] = gp[u];
+        }
     }
     __syncthreads();
     const float2 *khat = a.khat + (size_t)(a.khat_per_scene ? s * B + b : b) * p.Fy * (M + 1);
-    const size_t plane = (size_t)s * B + b;
-    const float2 *img = (const float2 *)(a.images + plane * HW);
-    const float2 *wgt = a.weights ? (const float2 *)(a.weights + plane * HW) : nullptr;
-    float2 *gp = (float2 *)(G + plane * HW);
     double loss = 0;
-    fft_conv_core<false>(l, p, khat, false);
-    SC_FFT_DISPATCH(p.R1x, (rows_Ainv_final<RR, true>(l, p, img, wgt, a.weight_scalar, gp, loss)))
-    fft_conv_core<true>(l, p, khat, true);
-    SC_FFT_DISPATCH(p.R1x, (rows_Ainv_final<RR, false>(l, p, img, wgt, a.weight_scalar, gp, loss)))
+    FFT_STAMP(31);
+    // the image is requested after the render's column stage: in flight under the next row pass
+    fft_conv_core<false>(l, p, khat, stamps, [&]() { if (p.dma_image) fft_dma_image(l, p, a.images + plane * HW); });
+    fft_residual(l, p, img, wgt, a.weight_scalar, loss);
+    FFT_STAMP(7);
+    fft_conv_core<true>(l, p, khat, stamps ? stamps + 8 : nullptr, []() {});
+    {
+        const float rcpw = 1.0f / (float)Wh;
+        for (int u = threadIdx.x; u < H * Wh; u += SC_FFT_NT) {
+            const int y = fast_div(u, rcpw), n = u - y * Wh;
+            gp[u] = l.A[y * p.RS + n];
+        }
+    }
+    FFT_STAMP(15);
     // loss of the plane
     loss = wave_sum(loss);
     if ((threadIdx.x & (SC_WAVE - 1)) == 0) red[threadIdx.x / SC_WAVE] = loss;

@@ -47,9 +47,9 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
-                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST"};
+                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -116,6 +116,21 @@ static int ensure_tables(void)
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(sc_nfl_table), t.data(), SC_NFL_MAX * sizeof(unsigned short)));
     done[dev] = true;
     return SCARLET_OK;
+}
+
+// compute units of the current device (cached per device index)
+static int device_cu_count(void)
+{
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 // LDS bytes of the per-component update kernel for an H x W image
@@ -775,6 +790,9 @@ static bool fft_make_plan(int H, int W, int Py, int Px, FftPlan *p)
     p->Py = Py; p->Px = Px; p->oky = oky; p->okx = okx;
     p->scale = (float)(1.0 / ((double)M * (double)Fy));
     p->tables = nullptr;
+    p->stagger_wgs = 0;
+    p->dma_image = 0;
+    p->tab_off = fft_tab_off(Fy, p->RS, H, W, false);
     return fft_lds_bytes(Fy, M, p->RS) <= LDS_LIMIT - 4096;
 }
 // twiddle / permutation tables of a plan, float64 -> float32 (layout: fftconv.h FftPlan::tables)
@@ -802,7 +820,7 @@ static bool psf_lds_possible(const scarlet_batch *b, FftPlan *p)
 // beyond ~150 + P pixels) -- except for the diagnostic switch PSF_HIPFFT, which forces the library path
 // and must not change during the life of a batch (it is read when the workspace is sized).
 static bool psf_use_lds(const scarlet_batch *b, FftPlan *p) { return psf_lds_possible(b, p) && !opt(OPT_PSF_HIPFFT); }
-struct PsfLayout { int64_t loss, real, spec, khat, lds_khat, lds_tables, total; };
+struct PsfLayout { int64_t loss, real, spec, khat, lds_khat, lds_tables, stamps, total; };
 static PsfLayout psf_layout(const scarlet_batch *b)
 {
     const PsfGeom g = psf_geom(b->H, b->W, b->psf_h, b->psf_w);
@@ -818,7 +836,9 @@ static PsfLayout psf_layout(const scarlet_batch *b)
     l.khat = l.spec + (want_hipfft ? align256(planes * g.Fy * g.Fxh * (int64_t)sizeof(float2)) : 0);
     l.lds_khat = l.khat + (want_hipfft ? align256(nk * g.Fy * g.Fxh * (int64_t)sizeof(float2)) : 0);
     l.lds_tables = l.lds_khat + (lds ? align256(nk * p.Fy * (p.M + 1) * (int64_t)sizeof(float2)) : 0);
-    l.total = l.lds_tables + (lds ? align256(fft_table_float2s(p.Fy, p.M) * (int64_t)sizeof(float2)) : 0) + 256;
+    l.stamps = l.lds_tables + (lds ? align256(fft_table_float2s(p.Fy, p.M) * (int64_t)sizeof(float2)) : 0);
+    // diagnostics (STAMPS switch, read when the workspace is sized): 32 shader-clock stamps per plane
+    l.total = l.stamps + ((lds && opt(OPT_STAMPS)) ? align256(planes * 32 * (int64_t)sizeof(long long)) : 0) + 256;
     return l;
 }
 
@@ -971,14 +991,22 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         // one kernel: model, render, residual + loss, adjoint -> compact gradient planes G [S][B][H][W] in `real`
         fp.tables = (const float2 *)((char *)b->workspace + l.lds_tables);
         a.khat = (const float2 *)((char *)b->workspace + l.lds_khat);
-        const size_t lds = fft_lds_bytes(fp.Fy, fp.M, fp.RS);
+        // the image plane is staged in LDS by LDS-DMA when it fits behind the H data rows (16-byte pieces)
+        fp.dma_image = ((b->H * b->W) % 4 == 0 &&
+                        fft_lds_bytes(fp.Fy, fp.M, fp.RS, b->H, b->W, true) <= LDS_LIMIT - 1024) ? 1 : 0;
+        fp.tab_off = fft_tab_off(fp.Fy, fp.RS, b->H, b->W, fp.dma_image != 0);
+        const size_t lds = fft_lds_bytes(fp.Fy, fp.M, fp.RS, b->H, b->W, fp.dma_image != 0);
         if ((rc = allow_lds(k_psf_conv, lds))) return rc;
         const int groups = (b->S + 7) / 8;
         prof_start(5, st);
-        hipLaunchKernelGGL(k_psf_conv, dim3(groups * 8 * b->B), dim3(SC_FFT_NT), lds, st, a, fp, a.real);
-        prof_stop(st);
-        // the gradient kernels below read G through the same geometry struct: compact planes, no offset
+        // model planes, compact [S][B][H][W], into `real` (k_psf_model with the geometry of an unpadded plane)
         a.g.Fy = b->H; a.g.Fx = b->W; a.g.Fxh = b->W / 2 + 1; a.g.oy = 0; a.g.ox = 0;
+        hipLaunchKernelGGL(k_psf_model, dim3((b->H * b->W + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
+        long long *stamps = opt(OPT_STAMPS) ? (long long *)((char *)b->workspace + l.stamps) : nullptr;
+        fp.stagger_wgs = 0;
+        hipLaunchKernelGGL(k_psf_conv, dim3(groups * 8 * b->B), dim3(SC_FFT_NT), lds, st, a, fp, a.real, stamps);
+        prof_stop(st);
+        // (the gradient kernels below read G through the same geometry struct: compact planes, no offset)
     } else {
     FftPlans p;
     rc = get_plans(g.Fy, g.Fx, planes, &p);

@@ -3,9 +3,11 @@
 # --kernel-trace only (MI355X_MICROARCH.md: 8 SQ slots per pass; FETCH_SIZE and WRITE_SIZE in passes of their own).
 #   usage: bash tools/pmc_any.sh <tag> <kernel substring> <python script> [args...]
 #   -> gpurun_out/pmc_<tag>.json  (per-launch means over the launches of that kernel)
-TAG=$1; KSUB=$2; shift 2
-cd /tmp && export TMPDIR=/tmp
+TAG=$1; KSUB=$2; SCRIPT=$3; shift 3
 R=$GRAFT_REPO_ROOT
+case "$SCRIPT" in /*) ;; *) SCRIPT=$R/$SCRIPT;; esac
+set -- "$SCRIPT" "$@"
+cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA" \

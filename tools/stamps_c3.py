@@ -1,0 +1,26 @@
+"""Phase stamps of k_psf_conv (SCARLET_STAMPS=1): shader-clock cycles per pass, mean over planes."""
+import sys, os
+os.environ["SCARLET_STAMPS"] = "1"
+os.environ.setdefault("PMC_SCENES", "4096"); os.environ["PMC_ITERS"] = "3"
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import runpy, numpy as np, torch
+g = runpy.run_path(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools", "pmc_run_c3.py"))
+b = g["b"]
+n = b.S * b.B * 32
+ws = b.workspace
+# the stamps region is the last one of the PSF layout (scarlet_hip.hip psf_layout): total - 256 - planes*32*8
+off = ws.numel() - 256 - ((n * 8 + 255) // 256) * 256
+st = ws[off:off + n * 8].view(torch.int64).view(-1, 32).cpu().numpy()
+ok = st[:, 15] > 0
+st = st[ok]
+names = ["start", "load model plane", "rowsA", "rowsB", "colsA+unt", "colsB*K*Binv", "colsAinv+tangle", "rowsBinv", "rowsAinv", "residual",
+         "rowsA", "rowsB", "colsA+unt", "colsB*K*Binv", "colsAinv+tangle", "rowsBinv", "rowsAinv", "store G"]
+seq = [30, 31, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]
+prev = st[:, 30]
+tot = (st[:, 15] - st[:, 30]).mean()
+print("planes stamped:", len(st), " total cycles per plane: %.0f" % tot)
+print("start-up detail (cycles since kernel start): prefetch issued %.0f, tables in LDS %.0f, zero fill %.0f, model stored %.0f, image requested %.0f, barrier %.0f" % tuple(
+    (st[:, i] - st[:, 30]).mean() for i in (16, 17, 18, 19, 20, 31)))
+for nm, i in zip(names[1:], seq[1:]):
+    d = (st[:, i] - prev).mean(); prev = st[:, i]
+    print("%-24s %8.0f  %5.1f%%" % (nm, d, 100 * d / tot))
