@@ -73,11 +73,15 @@ extern "C" {
 const char *scarlet_version(void);
 const char *scarlet_last_error(void);
 /* Diagnostic switches: NO_EXACT, NO_KSCACHE, FUSED_V1, NO_FUSED, FORCE_BLOCK_UPDATE,
- * NO_HYBRID_SWEEP, PAD_LDS, STAMPS, PSF_HIPFFT, NO_PERSIST, NO_STAGGER.  Each starts from the environment variable
+ * NO_HYBRID_SWEEP, PAD_LDS, STAMPS, PSF_HIPFFT, NO_PERSIST, NO_STAGGER, NO_BOX.  Each starts from the environment variable
  * SCARLET_<NAME>, read once at first use; afterwards only this call changes it.  Returns the
  * previous value (0 / 1) or SCARLET_E_ARG for an unknown name.  None changes results beyond
  * float32 rounding. */
 int scarlet_set_option(const char *name, int value);
+/* Diagnostics: with the STAMPS switch on, kernels that carry phase stamps (k_source_update_box: 16 shader-clock
+ * values per component) write them into a buffer owned by the library; this copies up to `capacity` of
+ * them to `out` (host) after a device synchronisation and returns the count (0 when the switch is off). */
+int64_t scarlet_debug_stamps(int64_t *out, int64_t capacity);
 /* 5-smooth fast FFT length (scipy.fftpack.next_fast_len as used by fft.py:99) */
 int scarlet_next_fast_len(int n);
 

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "scarlet_version": (c_char_p, []),
     "scarlet_last_error": (c_char_p, []),
     "scarlet_set_option": (c_int, [c_char_p, c_int]),
+    "scarlet_debug_stamps": (c_int64, [_P, c_int64]),
     "scarlet_next_fast_len": (c_int, [c_int]),
     "scarlet_host_prox_monotonic_f64": (c_int, [_P, c_int, _P, _P, c_int, c_double]),
     "scarlet_host_prox_weighted_monotonic_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_float]),

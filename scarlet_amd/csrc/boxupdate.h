@@ -1,0 +1,374 @@
+// boxupdate.h -- k_source_update_box: the constraint pipeline of PointSource/ExtendedSource.update
+// (source.py:402-440) for frames beyond the wave-level tile (H or W > 64, up to 256 x 256), computed ONLY
+// WHERE ITS RESULT CAN BE NON-ZERO.
+//
+// With the default pipeline (symmetry -> radial monotonicity -> positivity) the weighted sweep ends as soon
+// as three consecutive levels hold no positive value (wave_ops.h): every pixel beyond that level is capped
+// by non-positive neighbours and positivity zeroes it.  A sweep that ends by level 2 R = 62, i.e. within
+// SC_UB_R = 31 pixels of the peak -- the usual case: a source's footprint plus the few pixels the noise needs
+// to pull the envelope below zero -- therefore needs the symmetrised morphology only inside the 63 x 63 box
+// around the peak (a box of half-size R holds every pixel of the levels <= 2 R).
+// The k-space symmetry out = X/2 + (A X B + s (sigma sigma^T X) C)/2 (prox_ops.h) restricted to output
+// rows / columns of the box is two much smaller GEMMs,
+//     T = X B[:, box]   (h x w x 64)        Y = A[box, :] T   (64 x h x 64),
+// ~2.7 x fewer MFMAs than the full h x w x (h + w) products on a 128 x 128 window and ~6 x on 256 x 256, and
+// neither the frame-sized tile nor the frame-sized scratch has to live in LDS / HBM: X streams through LDS
+// once in bands of rows.  Each output element is accumulated over k in the same order as in
+// kspace_symmetry_tile, so inside the box the values are bit-identical to the full operator's.
+//
+// A component whose sweep does NOT end within the box (or the rare centred soft-symmetry window) is left
+// untouched and flagged in `fallback`; k_source_update<MODE> then runs for the flagged components only.
+#pragma once
+#include "engine.h"
+
+#define SC_UB_R 31                                   // box half-size: complete for the sweep levels <= 62
+#define SC_UB_LW (2 * SC_UB_R + 3)
+#define SC_UB_FLOATS ((2 * SC_UB_R + 1) * SC_UB_LW)
+#define SC_UB_N 64                                   // padded box side: four 16-wide MFMA tiles
+#define SC_UB_NT (SC_UB_N / 16)
+#define SC_UB_TS 64                                  // row stride of T; odd rows are stored with their column index ^ 16, so that
+                                                     // the MFMA B-operand reads (rows k, k + 1 in one lane group) hit 32 banks
+#define SC_UB_BR 16                                  // rows of X per band in LDS
+__device__ __forceinline__ int ub_tcol(int k, int j) { return j ^ ((k & 1) << 4); }
+
+__host__ __device__ inline size_t ub_lds_floats(int H, int W)
+{
+    const int hp = round16(H), wp = round16(W);
+    const size_t stage = (size_t)SC_UB_BR * tile_stride(wp);          // the band of X and the box share their space
+    return (stage > SC_UB_FLOATS ? stage : (size_t)SC_UB_FLOATS) + (size_t)hp * SC_UB_TS + 2 * hp + 4 * wp + wp + SC_UB_N;
+}
+
+__global__ __launch_bounds__(SC_BLOCK, 3) void k_source_update_box(UpdateArgs a, int *fallback, long long *stamps_all)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int c = blockIdx.x, s = c / a.K;
+    if (!a.force_it0 && !a.active[s]) return;
+    long long *stamps = stamps_all ? stamps_all + (size_t)c * 16 : nullptr;
+#define UB_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    UB_STAMP(0);
+    const int H = a.H, W = a.W, HW = H * W, B = a.B;
+    const int hpF = round16(H), wpF = round16(W);
+    const int BR = SC_UB_BR, SW = tile_stride(wpF);
+    float *stage = lds;                                   // [BR][SW]   band of X rows (GEMM 1) ...
+    float *box = lds;                                     // [63][65]   ... then the box around the peak
+    const size_t stage_floats_ = (size_t)BR * SW;
+    float *Tb = lds + (stage_floats_ > SC_UB_FLOATS ? stage_floats_ : (size_t)SC_UB_FLOATS);   // [hp][TS]   T = X B[:, box]
+    float *av = Tb + (size_t)hpF * SC_UB_TS, *bv = av + 2 * hpF, *cv = bv + 2 * wpF, *zv = cv + 2 * wpF, *vsum = zv + wpF;
+    __shared__ double red[SC_NWAVES];
+    __shared__ int ctr[2];
+    __shared__ double shf[2];
+    __shared__ int stat;
+    __shared__ int hyb[2];
+    const int c0 = a.cur[s];
+    const int wbuf = a.in_iteration ? 1 - c0 : c0;
+    float *gm = a.morph[wbuf] + (size_t)c * HW;
+    Tile tg; tg.H = H; tg.W = W; tg.LW = W; tg.m = gm;    // the stepped morphology, in place in HBM / L2
+    if (threadIdx.x == 0) stat = 0;
+    __syncthreads();
+    const int it = a.force_it0 ? 0 : a.it[s] + (a.in_iteration ? 1 : 0);
+    int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
+    if (threadIdx.x < SC_WAVE) {                                             // source.py:414 (25 lanes, one load each)
+        int st = 0;
+        wave_max_pixel(tg, cy, cx, st);
+        if (threadIdx.x == 0) { ctr[0] = cy; ctr[1] = cx; if (st) stat |= st; }
+    }
+    __syncthreads();
+    cy = ctr[0]; cx = ctr[1];
+    double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
+    bool new_shift = false;
+    if (a.symmetric && it % 5 == 0) {                                        // source.py:428-429
+        __syncthreads();
+        centroid_tile(tg, a.centroid_psf, a.centroid_P, cy, cx, red, ctr, shf, &stat);
+        cy = ctr[0]; cx = ctr[1]; dy = shf[0]; dx = shf[1];
+        new_shift = true;
+    }
+    UB_STAMP(1);
+    const SymWindow sw = sym_window(H, W, cy, cx);
+    // 0: no symmetry, 1: k-space, 2: soft flip (no shift yet)
+    const int mode = !a.symmetric ? 0 : ((dy != dy) ? 2 : (sw.centered ? 0 : 1));
+    if (mode == 2 && sw.centered) {                       // the flip about the array middle leaves the box: full path
+        if (threadIdx.x == 0) fallback[c] = 1;
+        return;
+    }
+    // the box, clipped to the frame (frame coordinates) ...
+    const int by0 = max(0, cy - SC_UB_R), bx0 = max(0, cx - SC_UB_R);
+    const int bh = min(H, cy + SC_UB_R + 1) - by0, bw = min(W, cx + SC_UB_R + 1) - bx0;
+    // ... and its part inside the symmetry window (window coordinates): rows [ia, ia + nbh), columns [ja, ja + nbw)
+    const int ia = max(by0 - sw.y0, 0), ja = max(bx0 - sw.x0, 0);
+    const int nbh = min(sw.h, by0 + bh - sw.y0) - ia, nbw = min(sw.w, bx0 + bw - sw.x0) - ja;
+    // global loads are requested as early as their addresses are known and consumed late: the box (X inside it,
+    // 16 values per thread) and the first band of window rows now, under the float64 trigonometry of the vectors
+    constexpr int NBX = (SC_UB_FLOATS / SC_UB_LW * (2 * SC_UB_R + 1) + SC_BLOCK - 1) / SC_BLOCK;      // 63 * 63 / 256 -> 16
+    float bxr[NBX];
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+        const int i = threadIdx.x + j * SC_BLOCK;
+        const int y = i / bw, x = i - y * bw;
+        bxr[j] = i < bh * bw ? gm[(by0 + y) * W + bx0 + x] : 0.f;
+    }
+    Tile bt; bt.H = bh; bt.W = bw; bt.LW = SC_UB_LW; bt.m = box;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+    const int hW = sw.h, wW = sw.w, wpW = round16(wW);
+    // band of BR window rows x wp columns: element e = threadIdx.x + j * 256 -> (row e / wp, column e % wp)
+    constexpr int NBAND = SC_UB_BR * 256 / SC_BLOCK;             // values per thread for the widest frame (wp = 256)
+    float xr[NBAND];
+    auto load_band = [&](int i0) {
+#pragma unroll
+        for (int j = 0; j < NBAND; ++j) {
+            const int e = threadIdx.x + j * SC_BLOCK;
+            const int r = e / wpW, cc = e - r * wpW;
+            xr[j] = (e < SC_UB_BR * wpW && i0 + r < hW && cc < wW) ? gm[(sw.y0 + i0 + r) * W + sw.x0 + cc] : 0.f;
+        }
+    };
+    if (mode == 1) load_band(0);
+    auto store_box = [&]() {
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) {
+            const int i = threadIdx.x + j * SC_BLOCK;
+            const int y = i / bw, x = i - y * bw;
+            if (i < bh * bw) box[y * SC_UB_LW + x] = bxr[j];
+        }
+    };
+    if (mode == 1) {
+        const int h = sw.h, w = sw.w, ry = h / 2, rx = w / 2;
+        const int hp = round16(h), wp = round16(w);
+        const int Fy = dev_next_fast_len(2 * h + 10);
+        int Fx = dev_next_fast_len(2 * w + 10);
+        while (Fx & 1) Fx = dev_next_fast_len(Fx + 1);
+        kspace_vectors(av, bv, cv, hp, wp, ry, rx, h, w, Fy, Fx, dy, dx);
+        const float sy = (Fy & 1) ? 0.f : (float)(sinpi(2.0 * dy) / Fy);
+        const bool need_rank1 = (sy != 0.f);
+        float vloc = 0.f;
+        UB_STAMP(2);
+        // GEMM 1: T[:, box columns] = X (h x w, zero outside the window) . Hankel(bv); X streams through `stage`
+        const int NRT = BR >> 4, G = SC_NWAVES / NRT;             // row tiles per band, column groups
+        const int rt = wid % NRT, grp = wid / NRT;
+        for (int i0 = 0; i0 < hp; i0 += BR) {
+            __syncthreads();                                       // vectors ready / previous band consumed
+#pragma unroll
+            for (int j = 0; j < NBAND; ++j) {
+                const int e = threadIdx.x + j * SC_BLOCK;
+                const int r = e / wp, cc = e - r * wp;
+                if (e < BR * wp) stage[r * SW + cc] = xr[j];
+            }
+            __syncthreads();
+            if (i0 + BR < hp) load_band(i0 + BR);                  // the next band: in flight under this band's MFMAs
+            if (need_rank1 && threadIdx.x < w) {                   // v[j] = sum_i (-1)^(i - ry) X[i][j], i ascending
+                const int rows = min(BR, h - i0);
+                for (int r = 0; r < rows; ++r) {
+                    const float x = stage[r * SW + threadIdx.x];
+                    vloc += ((i0 + r - ry) & 1) ? -x : x;
+                }
+            }
+            if (i0 + rt * 16 < hp) {
+                f32x4 acc[SC_UB_NT];
+#pragma unroll
+                for (int ct = 0; ct < SC_UB_NT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float *arow = stage + (rt * 16 + lr) * SW;
+#pragma unroll 4
+                for (int k0 = 0; k0 < wp; k0 += 4) {
+                    const int k = k0 + lq;
+                    const float xa = arow[k];
+#pragma unroll
+                    for (int ct = 0; ct < SC_UB_NT; ++ct)
+                        if (ct % G == grp)
+                            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, bv[min(k + ja + ct * 16 + lr, 2 * wp - 1)], acc[ct], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ct = 0; ct < SC_UB_NT; ++ct)
+                    if (ct % G == grp)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = i0 + rt * 16 + lq * 4 + r;
+                            Tb[row * SC_UB_TS + ub_tcol(row, ct * 16 + lr)] = acc[ct][r];
+                        }
+            }
+        }
+        if (need_rank1 && threadIdx.x < wp) zv[threadIdx.x] = threadIdx.x < w ? vloc : 0.f;
+        __syncthreads();                                           // T and v complete; the last band is consumed
+        store_box();                                               // (the box takes the band's place; read from GEMM 2's epilogue on)
+        UB_STAMP(3);
+        if (need_rank1 && threadIdx.x < SC_UB_N) {                 // z[j] = sum_j2 C[j][j2] v[j2] for the box columns
+            const int j = ja + threadIdx.x;
+            float zloc = 0.f;
+            if (j < w)
+                for (int j2 = 0; j2 < w; ++j2) zloc += cv[j + j2] * zv[j2];
+            vsum[threadIdx.x] = zloc;
+        }
+        __syncthreads();
+        UB_STAMP(4);
+        // GEMM 2: Y[box rows, box columns] = Hankel(av)[box rows, :] . T ; epilogue combines with X in the box
+        for (int tile = wid; tile < SC_UB_NT * SC_UB_NT; tile += SC_NWAVES) {
+            const int rt2 = tile / SC_UB_NT, ct2 = tile - rt2 * SC_UB_NT;
+            if (rt2 * 16 >= nbh || ct2 * 16 >= nbw) continue;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int ai = ia + rt2 * 16 + lr;
+#pragma unroll 4
+            for (int k0 = 0; k0 < hp; k0 += 4) {
+                const int k = k0 + lq;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[min(ai + k, 2 * hp - 1)], Tb[k * SC_UB_TS + ub_tcol(k, ct2 * 16 + lr)], acc, 0, 0, 0);
+            }
+            const int jl = ct2 * 16 + lr, j = ja + jl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = rt2 * 16 + lq * 4 + r, i = ia + il;
+                if (il < nbh && jl < nbw) {
+                    float *p = &box[(sw.y0 + i - by0) * SC_UB_LW + (sw.x0 + j - bx0)];
+                    const float x = *p;
+                    float y2 = acc[r];
+                    if (need_rank1) y2 += (((i - ry) & 1) ? -sy : sy) * vsum[jl];
+                    *p = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
+                }
+            }
+        }
+        __syncthreads();
+    } else if (mode == 2) {
+        store_box();
+        // soft symmetry, strength 1 (operator.py:242-251) on the part of the window inside the box: a pixel and
+        // its point reflection about the peak are both in it
+        const int n = nbh * nbw;
+        const float aa = 0.5f, bq = 0.f;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += SC_BLOCK) {
+            const int j = n - 1 - i;
+            if (j < i) break;
+            const int iy = i / nbw, ix = i - iy * nbw, jy = j / nbw, jx = j - jy * nbw;
+            float *pi = &box[(sw.y0 + ia + iy - by0) * SC_UB_LW + (sw.x0 + ja + ix - bx0)];
+            float *pj = &box[(sw.y0 + ia + jy - by0) * SC_UB_LW + (sw.x0 + ja + jx - bx0)];
+            const float xi = *pi, xj = *pj;
+            const float si = xi + xj, sj = xj + xi;
+            *pi = aa * si + bq * xi;
+            *pj = aa * sj + bq * xj;
+        }
+        __syncthreads();
+    } else {
+        store_box();
+        __syncthreads();
+    }
+    UB_STAMP(5);
+    // the previous morphology for the convergence sums: the first groups are requested now, under the sweep
+    const float *gl = a.in_iteration ? a.morph[c0] + (size_t)c * HW : nullptr;
+    constexpr int NLAST = 16;
+    float4 lastv[NLAST];
+    const bool vec4 = (W & 3) == 0;
+    if (vec4) {
+#pragma unroll
+        for (int j = 0; j < NLAST; ++j) {
+            const int g = threadIdx.x + j * SC_BLOCK;
+            lastv[j] = (gl && g < (HW >> 2)) ? reinterpret_cast<const float4 *>(gl)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // radial monotonicity on the box: levels 1 .. 62, one wave, no barriers
+    if (threadIdx.x < SC_WAVE) {
+        int done, quiet;
+        wave_monotonic<float>(bt, cy - by0, cx - bx0, 0.f, &done, &quiet, 0.f, 2 * SC_UB_R);
+        if (threadIdx.x == 0) { hyb[0] = done; hyb[1] = quiet; }
+    }
+    __syncthreads();
+    const int lstop = hyb[0];
+    UB_STAMP(6);
+    if (stamps && threadIdx.x == 0) stamps[8] = lstop;
+    if (lstop == (1 << 30)) {                              // the footprint leaves the box: full path, nothing written yet
+        if (threadIdx.x == 0) fallback[c] = 1;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        fallback[c] = 0;
+        a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx;
+        if (new_shift) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
+    }
+    // sparse_l0 / sparse_l1, positive, normalized('morph_max') (update.py:71-82, 27-32, 62-65): as k_source_update
+    const float step_morph = 1.0f / (float)a.lipschitz[2 * s + 1];
+    const float l0 = a.l0_thresh >= 0.f ? a.l0_thresh * step_morph : -1.f;
+    const float l1 = a.l1_thresh >= 0.f ? a.l1_thresh * step_morph : -1.f;
+    auto sparse_plus = [&](float v, int y, int x) {
+        if (l0 >= 0.f && fabsf(v) < l0) v = 0.f;
+        if (l1 >= 0.f) {
+            const float mag = fabsf(v) - l1;
+            v = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * (mag < 0.f ? 0.f : mag);
+        }
+        if (v < 0.f || sweep_level(y, x, cy, cx) > lstop) v = 0.f;
+        return v;
+    };
+    float norm = sparse_plus(box[(cy - by0) * SC_UB_LW + (cx - bx0)], cy, cx);
+    const bool regular = norm > 0.f && !isinf(norm);
+    const float rnorm = 1.0f / norm;
+    float d2f = 0.f, n2f = 0.f;
+    auto out_pixel = [&](int y, int x) {
+        // outside the box: level >= 2 (R + 1) > lstop -> 0 (0 / norm keeps the reference's NaN when norm is 0 or NaN)
+        float v = 0.f;
+        const int yb = y - by0, xb = x - bx0;
+        if ((unsigned)yb < (unsigned)bh && (unsigned)xb < (unsigned)bw) v = sparse_plus(box[yb * SC_UB_LW + xb], y, x);
+        if (regular) { const float q = v * rnorm; return fmaf(fmaf(-q, norm, v), rnorm, q); }
+        return v / norm;
+    };
+    if (vec4) {
+        const int gpr = W >> 2, ngroups = HW >> 2;
+        auto do_group = [&](int g, const float4 &l) {
+            const int y = g / gpr, x = (g - y * gpr) << 2;
+            float o[4];
+            if (regular && (y < by0 || y >= by0 + bh || x + 3 < bx0 || x >= bx0 + bw)) { o[0] = o[1] = o[2] = o[3] = 0.f; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = out_pixel(y, x + e);
+            }
+            reinterpret_cast<float4 *>(gm)[g] = make_float4(o[0], o[1], o[2], o[3]);
+            if (gl) {
+                const float e0 = l.x - o[0], e1 = l.y - o[1], e2 = l.z - o[2], e3 = l.w - o[3];
+                d2f += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+            }
+            n2f += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+        };
+#pragma unroll
+        for (int j = 0; j < NLAST; ++j) {
+            const int g = threadIdx.x + j * SC_BLOCK;
+            if (g < ngroups) do_group(g, lastv[j]);
+        }
+        // larger frames: the remaining groups in chunks of NLAST, loads of a chunk together before its stores
+        for (int g0 = NLAST * SC_BLOCK; g0 < ngroups; g0 += NLAST * SC_BLOCK) {
+#pragma unroll
+            for (int j = 0; j < NLAST; ++j) {
+                const int g = g0 + threadIdx.x + j * SC_BLOCK;
+                lastv[j] = (gl && g < ngroups) ? reinterpret_cast<const float4 *>(gl)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < NLAST; ++j) {
+                const int g = g0 + threadIdx.x + j * SC_BLOCK;
+                if (g < ngroups) do_group(g, lastv[j]);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += SC_BLOCK) {
+            const int y = i / W, x = i - y * W;
+            const float o = out_pixel(y, x);
+            gm[i] = o;
+            if (gl) { const float d = gl[i] - o; d2f += d * d; }
+            n2f += o * o;
+        }
+    }
+    double d2 = block_sum((double)d2f, red), n2 = block_sum((double)n2f, red);
+    if (n2 != n2 && norm == norm) {
+        norm = __builtin_nanf("");
+        for (int i = threadIdx.x; i < HW; i += SC_BLOCK) gm[i] = norm;
+        d2 = norm;
+    }
+    if (threadIdx.x == 0 && (!(norm > 0.f) || isinf(norm))) stat |= SCARLET_STATUS_NONFINITE;
+    if (threadIdx.x == 0) {
+        float *gs = a.sed[wbuf] + (size_t)c * B;
+        const float *gsl = a.in_iteration ? a.sed[c0] + (size_t)c * B : nullptr;
+        double d2s = 0, n2s = 0;
+        for (int b = 0; b < B; ++b) {
+            float v = gs[b];
+            if (v < 0.f) v = 0.f;
+            v = v * norm;
+            gs[b] = v;
+            if (gsl) { const float d = gsl[b] - v; d2s += (double)(d * d); }
+            n2s += (double)(v * v);
+        }
+        a.conv[4 * c + 0] = d2s; a.conv[4 * c + 1] = n2s;
+        a.conv[4 * c + 2] = d2;  a.conv[4 * c + 3] = n2;
+        if (stat) atomicOr(&a.status[s], stat);
+    }
+    UB_STAMP(7);
+#undef UB_STAMP
+}

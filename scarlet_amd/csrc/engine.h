@@ -474,6 +474,7 @@ struct UpdateArgs {
     int force_it0;                    // 1: constructor call (it = 0, ignore `active`)
     float *gscratch;                  // GT kernels: [S*K][round16(H) * scratch_stride(round16(W))] (T = X B)
     int hybrid_sweep;                 // LDS tiles: sweep levels 1 .. 46 on one wave (wave_monotonic), the rest on the workgroup
+    const int *only_flagged;          // [S*K] or NULL: run only for the components k_source_update_box left to the full path
 };
 
 // MODE 0/1: the morphology tile lives in LDS (tiles up to ~128 x 128).
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
     extern __shared__ __align__(16) float lds[];
     const int c = blockIdx.x, s = c / a.K;
     if (!a.force_it0 && !a.active[s]) return;
+    if (a.only_flagged && !a.only_flagged[c]) return;
     const int H = a.H, W = a.W, HW = H * W, B = a.B;
     const int hp = round16(H), wp = round16(W);
     Tile t; t.H = H; t.W = W;

@@ -19,6 +19,7 @@
 #include "fused.h"
 #include "fused2.h"
 #include "bigk.h"
+#include "boxupdate.h"
 #include "psf_path.h"
 #include "fftconv.h"
 #include "extras.h"
@@ -47,9 +48,9 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
-                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER"};
+                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER", "NO_BOX"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -116,6 +117,34 @@ static int ensure_tables(void)
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(sc_nfl_table), t.data(), SC_NFL_MAX * sizeof(unsigned short)));
     done[dev] = true;
     return SCARLET_OK;
+}
+
+// diagnostics (STAMPS switch): a device buffer of shader-clock stamps owned by the library, read back with
+// scarlet_debug_stamps; NULL when the switch is off
+static long long *g_dbg_stamps = nullptr;
+static size_t g_dbg_count = 0;
+static std::mutex g_dbg_mu;
+static long long *debug_stamps(size_t count)
+{
+    if (!opt(OPT_STAMPS)) return nullptr;
+    std::lock_guard<std::mutex> lock(g_dbg_mu);
+    if (count > g_dbg_count) {
+        if (g_dbg_stamps) (void)hipFree(g_dbg_stamps);
+        g_dbg_stamps = nullptr; g_dbg_count = 0;
+        if (hipMalloc((void **)&g_dbg_stamps, count * sizeof(long long)) != hipSuccess) return nullptr;
+        g_dbg_count = count;
+    }
+    (void)hipMemset(g_dbg_stamps, 0, g_dbg_count * sizeof(long long));
+    return g_dbg_stamps;
+}
+extern "C" int64_t scarlet_debug_stamps(int64_t *out, int64_t capacity)
+{
+    std::lock_guard<std::mutex> lock(g_dbg_mu);
+    if (!g_dbg_stamps || !out) return 0;
+    const int64_t n = capacity < (int64_t)g_dbg_count ? capacity : (int64_t)g_dbg_count;
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(out, g_dbg_stamps, n * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
 }
 
 // compute units of the current device (cached per device index)
@@ -746,8 +775,8 @@ static int64_t base_workspace_bytes(const scarlet_batch *b)
     const int64_t P = n_partials(b->K, b->B);
     // K > 8 (bigk.h): one scratch plane set [S][B][HW] for G = w^2 (model - image)
     const int64_t resid = b->K > SC_KMAX ? align256(sizeof(float) * (int64_t)b->S * b->B * b->H * b->W) : 0;
-    return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4)) + resid +
-           gscratch_bytes(b) + kscache_bytes(b) + 256;
+    return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4) + sizeof(int) * (int64_t)b->S * b->K) +
+           resid + gscratch_bytes(b) + kscache_bytes(b) + 256;
 }
 // ---- LDS-resident convolution (fftconv.h): plan = lengths, radices, kernel placement
 // smallest circular length that reproduces the cropped linear convolution: image at 0..N-1, kernel at
@@ -859,8 +888,10 @@ static float *ws_resid(const scarlet_batch *b)
 {
     const int64_t P = n_partials(b->K, b->B);
     return (float *)((char *)b->workspace +
-                     align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4)));
+                     align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4) + sizeof(int) * (int64_t)b->S * b->K));
 }
+// per component: 1 = k_source_update_box left it to the full-frame kernel (behind the convergence sums)
+static int *ws_box_fallback(const scarlet_batch *b) { return (int *)(ws_conv(b) + (size_t)b->S * b->K * 4); }
 
 static float *ws_gscratch(const scarlet_batch *b)
 {
@@ -1218,7 +1249,19 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
     u.l0_thresh = b->l0_thresh; u.l1_thresh = b->l1_thresh;
     u.centroid_psf = b->centroid_psf; u.centroid_P = b->centroid_P; u.conv = ws_conv(b); u.force_it0 = force_it0;
     u.gscratch = nullptr;
+    u.only_flagged = nullptr;
     u.hybrid_sweep = opt(OPT_NO_HYBRID_SWEEP) ? 0 : 1;
+    if ((b->H > 64 || b->W > 64) && b->H <= 256 && b->W <= 256 && b->monotonic && !opt(OPT_NO_BOX) &&
+        sizeof(float) * ub_lds_floats(b->H, b->W) <= LDS_LIMIT) {
+        // frames beyond the wave-level tile: the pipeline on the box around each peak (boxupdate.h); the kernels
+        // below then run only for the components whose footprint left the box
+        const size_t ldsb = sizeof(float) * ub_lds_floats(b->H, b->W);
+        rc = allow_lds(k_source_update_box, ldsb);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_source_update_box, dim3(b->S * b->K), dim3(SC_BLOCK), ldsb, (hipStream_t)stream, u, ws_box_fallback(b),
+                           debug_stamps((size_t)b->S * b->K * 16));
+        u.only_flagged = ws_box_fallback(b);
+    }
     if (b->H <= 64 && b->W <= 64 && !opt(OPT_FORCE_BLOCK_UPDATE)) {
         // one wave per component, four components per workgroup (wave_ops.h)
         const size_t lds = sizeof(float) * SC_NWAVES * ((size_t)b->H * tile_stride(b->W) + SC_WAVE_VEC_FLOATS);

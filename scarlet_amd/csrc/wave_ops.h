@@ -242,9 +242,12 @@ __device__ __forceinline__ Walker<T> make_compact_walker(int e, int H, int W, in
 // trailing levels without a positive value, for a caller that continues the sweep from level 47 itself.
 // `floor`: the early exit counts values above it (0: the caller applies positivity; the detection cut of the
 // source initialisation, which zeroes everything <= cut).
+// `level_cap` > SC_COMPACT_LAST (with quiet_out): the sweep continues through the two-trip levels up to
+// level_cap and reports there -- for a caller whose tile is a box around the peak that is complete only up to
+// that level (boxupdate.h).
 template <typename T>
 __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thresh, int *last_level = nullptr,
-                                      int *quiet_out = nullptr, T floor = (T)0)
+                                      int *quiet_out = nullptr, T floor = (T)0, int level_cap = 0)
 {
     const int H = t.H, W = t.W, LW = t.LW;
     T *m = t.m;
@@ -343,7 +346,8 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         }
     }
     if (quiet_out) *quiet_out = quiet;
-    if (!stop && ell <= Lall && !quiet_out) {
+    const int Lend = level_cap > SC_COMPACT_LAST ? min(Lall, level_cap) : Lall;
+    if (!stop && ell <= Lend && (!quiet_out || level_cap > SC_COMPACT_LAST)) {
         // ---- levels 47 ..: two trips per level (right/left wedges, then down/up), one walker
         // per 32-lane half and level parity.  (ell == 47 here.)
         const int half = lane >> 5, k2 = (lane & 31) << 1;
@@ -354,7 +358,7 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
         WalkState<T> sx0 = walk_from(wx0, ell + 1, mb), sx1 = walk_from(wx1, ell, mb);
         WalkState<T> sy0 = walk_from(wy0, ell + 1, mb), sy1 = walk_from(wy1, ell, mb);
         Prep pa = prepare(sx1, wx1), pb = prepare(sy1, wy1);
-        while (ell <= Lall) {
+        while (ell <= Lend) {
             Prep na, nb;
             {   // odd level
                 const Vals va = load(pa, wx1), vb = load(pb, wy1);
@@ -366,7 +370,7 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
                 if (early && quiet >= 3) { stop = true; break; }
                 ++ell;
             }
-            if (ell > Lall) break;
+            if (ell > Lend) break;
             {   // even level
                 const Vals va = load(na, wx0), vb = load(nb, wy0);
                 pa = prepare(sx1, wx1); pb = prepare(sy1, wy1);
@@ -379,6 +383,7 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
             }
         }
     }
+    if (quiet_out && level_cap > SC_COMPACT_LAST) *quiet_out = quiet;
     if (stop) done = ell;                        // the last level that was computed
     if (last_level) *last_level = done;
 }
