@@ -26,19 +26,25 @@
 #define SC_UB_FLOATS ((2 * SC_UB_R + 1) * SC_UB_LW)
 #define SC_UB_N 64                                   // padded box side: four 16-wide MFMA tiles
 #define SC_UB_NT (SC_UB_N / 16)
-#define SC_UB_TS 64                                  // row stride of T; odd rows are stored with their column index ^ 16, so that
-                                                     // the MFMA B-operand reads (rows k, k + 1 in one lane group) hit 32 banks
 #define SC_UB_BR 16                                  // rows of X per band in LDS
-__device__ __forceinline__ int ub_tcol(int k, int j) { return j ^ ((k & 1) << 4); }
+// T = X B[:, box] never leaves the registers: wave w owns the 16 box columns 16 w .. 16 w + 15 of T for ALL
+// window rows (one MFMA accumulator per band of 16 rows), and the accumulator layout -- lane (lr, lq), element
+// r holds T[16 band + 4 lq + r][16 w + lr] -- is exactly a B operand of the second product when its k steps
+// enumerate (band, r): k(lq) = 16 band + 4 lq + r.  The Hankel operand A[i][k] = av[i + k] is read at that k.
+// (A permuted summation order over k; the values of T are bit-identical to kspace_symmetry_tile's.)
+// Measured alternatives (profiles/r02_notes.md): T in LDS (41 KB: two or three workgroups per CU instead of
+// four) 1.1 - 1.6 x slower; bands of 32 rows with two accumulation chains per wave spill at 128 VGPRs, slower.
 
 __host__ __device__ inline size_t ub_lds_floats(int H, int W)
 {
     const int hp = round16(H), wp = round16(W);
     const size_t stage = (size_t)SC_UB_BR * tile_stride(wp);          // the band of X and the box share their space
-    return (stage > SC_UB_FLOATS ? stage : (size_t)SC_UB_FLOATS) + (size_t)hp * SC_UB_TS + 2 * hp + 4 * wp + wp + SC_UB_N;
+    return (stage > SC_UB_FLOATS ? stage : (size_t)SC_UB_FLOATS) + 2 * hp + 4 * wp + wp + SC_UB_N;
 }
 
-__global__ __launch_bounds__(SC_BLOCK, 3) void k_source_update_box(UpdateArgs a, int *fallback, long long *stamps_all)
+// NB: bands of 16 window rows the kernel is built for (8: frames up to 128 rows, 16: up to 256)
+template <int NB>
+__global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a, int *fallback, long long *stamps_all)
 {
     extern __shared__ __align__(16) float lds[];
     const int c = blockIdx.x, s = c / a.K;
@@ -52,8 +58,7 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void k_source_update_box(UpdateArgs a,
     float *stage = lds;                                   // [BR][SW]   band of X rows (GEMM 1) ...
     float *box = lds;                                     // [63][65]   ... then the box around the peak
     const size_t stage_floats_ = (size_t)BR * SW;
-    float *Tb = lds + (stage_floats_ > SC_UB_FLOATS ? stage_floats_ : (size_t)SC_UB_FLOATS);   // [hp][TS]   T = X B[:, box]
-    float *av = Tb + (size_t)hpF * SC_UB_TS, *bv = av + 2 * hpF, *cv = bv + 2 * wpF, *zv = cv + 2 * wpF, *vsum = zv + wpF;
+    float *av = lds + (stage_floats_ > SC_UB_FLOATS ? stage_floats_ : (size_t)SC_UB_FLOATS), *bv = av + 2 * hpF, *cv = bv + 2 * wpF, *zv = cv + 2 * wpF, *vsum = zv + wpF;
     __shared__ double red[SC_NWAVES];
     __shared__ int ctr[2];
     __shared__ double shf[2];
@@ -140,48 +145,38 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void k_source_update_box(UpdateArgs a,
         const bool need_rank1 = (sy != 0.f);
         float vloc = 0.f;
         UB_STAMP(2);
-        // GEMM 1: T[:, box columns] = X (h x w, zero outside the window) . Hankel(bv); X streams through `stage`
-        const int NRT = BR >> 4, G = SC_NWAVES / NRT;             // row tiles per band, column groups
-        const int rt = wid % NRT, grp = wid / NRT;
-        for (int i0 = 0; i0 < hp; i0 += BR) {
-            __syncthreads();                                       // vectors ready / previous band consumed
+        // GEMM 1: T[:, box columns] = X (h x w, zero outside the window) . Hankel(bv); X streams through `stage`,
+        // wave `wid` accumulates the box columns 16 wid .. 16 wid + 15 for every band (registers)
+        f32x4 Tacc[NB];
 #pragma unroll
-            for (int j = 0; j < NBAND; ++j) {
-                const int e = threadIdx.x + j * SC_BLOCK;
-                const int r = e / wp, cc = e - r * wp;
-                if (e < BR * wp) stage[r * SW + cc] = xr[j];
-            }
-            __syncthreads();
-            if (i0 + BR < hp) load_band(i0 + BR);                  // the next band: in flight under this band's MFMAs
-            if (need_rank1 && threadIdx.x < w) {                   // v[j] = sum_i (-1)^(i - ry) X[i][j], i ascending
-                const int rows = min(BR, h - i0);
-                for (int r = 0; r < rows; ++r) {
-                    const float x = stage[r * SW + threadIdx.x];
-                    vloc += ((i0 + r - ry) & 1) ? -x : x;
+        for (int bi = 0; bi < NB; ++bi) {
+            const int i0 = bi * SC_UB_BR;
+            Tacc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (i0 < hp) {
+                __syncthreads();                                   // vectors ready / previous band consumed
+#pragma unroll
+                for (int j = 0; j < NBAND; ++j) {
+                    const int e = threadIdx.x + j * SC_BLOCK;
+                    const int r = e / wp, cc = e - r * wp;
+                    if (e < BR * wp) stage[r * SW + cc] = xr[j];
                 }
-            }
-            if (i0 + rt * 16 < hp) {
-                f32x4 acc[SC_UB_NT];
-#pragma unroll
-                for (int ct = 0; ct < SC_UB_NT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const float *arow = stage + (rt * 16 + lr) * SW;
+                __syncthreads();
+                if (i0 + BR < hp) load_band(i0 + BR);              // the next band: in flight under this band's MFMAs
+                if (need_rank1 && threadIdx.x < w) {               // v[j] = sum_i (-1)^(i - ry) X[i][j], i ascending
+                    const int rows = min(BR, h - i0);
+                    for (int r = 0; r < rows; ++r) {
+                        const float x = stage[r * SW + threadIdx.x];
+                        vloc += ((i0 + r - ry) & 1) ? -x : x;
+                    }
+                }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float *arow = stage + lr * SW;
 #pragma unroll 4
                 for (int k0 = 0; k0 < wp; k0 += 4) {
                     const int k = k0 + lq;
-                    const float xa = arow[k];
-#pragma unroll
-                    for (int ct = 0; ct < SC_UB_NT; ++ct)
-                        if (ct % G == grp)
-                            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, bv[min(k + ja + ct * 16 + lr, 2 * wp - 1)], acc[ct], 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k], bv[min(k + ja + wid * 16 + lr, 2 * wp - 1)], acc, 0, 0, 0);
                 }
-#pragma unroll
-                for (int ct = 0; ct < SC_UB_NT; ++ct)
-                    if (ct % G == grp)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = i0 + rt * 16 + lq * 4 + r;
-                            Tb[row * SC_UB_TS + ub_tcol(row, ct * 16 + lr)] = acc[ct][r];
-                        }
+                Tacc[bi] = acc;
             }
         }
         if (need_rank1 && threadIdx.x < wp) zv[threadIdx.x] = threadIdx.x < w ? vloc : 0.f;
@@ -197,17 +192,30 @@ __global__ __launch_bounds__(SC_BLOCK, 3) void k_source_update_box(UpdateArgs a,
         }
         __syncthreads();
         UB_STAMP(4);
-        // GEMM 2: Y[box rows, box columns] = Hankel(av)[box rows, :] . T ; epilogue combines with X in the box
-        for (int tile = wid; tile < SC_UB_NT * SC_UB_NT; tile += SC_NWAVES) {
-            const int rt2 = tile / SC_UB_NT, ct2 = tile - rt2 * SC_UB_NT;
+        // GEMM 2: Y[box rows, box columns] = Hankel(av)[box rows, :] . T ; epilogue combines with X in the box.
+        // Wave `wid`: its column tile of T from the accumulators, the four row tiles of the box.
+        f32x4 Y[SC_UB_NT];
+#pragma unroll
+        for (int rt2 = 0; rt2 < SC_UB_NT; ++rt2) Y[rt2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ct2 = wid;
+        if (ct2 * 16 < nbw) {
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi)
+                if (bi * 16 < hp) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = bi * 16 + 4 * lq + r;
+                        const float tb = Tacc[bi][r];
+#pragma unroll
+                        for (int rt2 = 0; rt2 < SC_UB_NT; ++rt2)
+                            Y[rt2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[min(ia + rt2 * 16 + lr + k, 2 * hp - 1)], tb, Y[rt2], 0, 0, 0);
+                    }
+                }
+        }
+#pragma unroll
+        for (int rt2 = 0; rt2 < SC_UB_NT; ++rt2) {
             if (rt2 * 16 >= nbh || ct2 * 16 >= nbw) continue;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const int ai = ia + rt2 * 16 + lr;
-#pragma unroll 4
-            for (int k0 = 0; k0 < hp; k0 += 4) {
-                const int k = k0 + lq;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[min(ai + k, 2 * hp - 1)], Tb[k * SC_UB_TS + ub_tcol(k, ct2 * 16 + lr)], acc, 0, 0, 0);
-            }
+            const f32x4 acc = Y[rt2];
             const int jl = ct2 * 16 + lr, j = ja + jl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

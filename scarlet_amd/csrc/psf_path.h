@@ -310,6 +310,232 @@ __global__ __launch_bounds__(SC_BLOCK) void k_step_psf(PsfArgs a)
     }
 }
 
+// ---- the same two kernels for COMPACT gradient planes G [S][B][H*W] (the LDS-resident convolution writes
+// them unpadded): 16 B per lane on every stream (K morphologies, B planes of G, K morphologies out) instead of
+// 4 B -- the scalar forms move 3.3 TB/s on BASELINE config 3, these are bound by HBM.  H * W % 4 == 0.
+template <int KM, int BM>
+__global__ __launch_bounds__(SC_BLOCK) void k_grad_psf4(PsfArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.g.H * a.g.W;
+    __shared__ double red[SC_NWAVES][KM * BM + KM * (KM + 1) / 2];
+    const int c0 = a.cur[s];
+    float dsed[KM][BM], gram[KM * (KM + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b) dsed[k][b] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KM * (KM + 1) / 2; ++i) gram[i] = 0.f;
+    const float4 *mor = reinterpret_cast<const float4 *>(a.morph[c0] + (size_t)s * K * HW);
+    const float4 *G = reinterpret_cast<const float4 *>(a.real + (size_t)s * B * HW);
+    const int HW4 = HW >> 2;
+    const int g_end = min(HW4, (tile + 1) * (SC_TILE_PIX >> 2));
+    for (int g = tile * (SC_TILE_PIX >> 2) + threadIdx.x; g < g_end; g += SC_BLOCK) {
+        float4 m[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) m[k] = k < K ? mor[(size_t)k * HW4 + g] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int b = 0; b < BM; ++b)
+            if (b < B) {
+                const float4 gg = G[(size_t)b * HW4 + g];
+                // pixel order inside the group as in the scalar kernel: x, y, z, w
+#pragma unroll
+                for (int k = 0; k < KM; ++k) {
+                    dsed[k][b] += gg.x * m[k].x; dsed[k][b] += gg.y * m[k].y;
+                    dsed[k][b] += gg.z * m[k].z; dsed[k][b] += gg.w * m[k].w;
+                }
+            }
+        int gi = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < KM; ++k2) {
+                gram[gi] += m[k].x * m[k2].x; gram[gi] += m[k].y * m[k2].y;
+                gram[gi] += m[k].z * m[k2].z; gram[gi] += m[k].w * m[k2].w;
+                ++gi;
+            }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b)
+            if (k < K && b < B) {
+                const double v = wave_sum((double)dsed[k][b]);
+                if (lane == 0) red[wid][k * B + b] = v;
+            }
+    {
+        int gi = 0, go = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < KM; ++k2) {
+                if (k < K && k2 < K) {
+                    const double v = wave_sum((double)gram[gi]);
+                    if (lane == 0) red[wid][K * B + go] = v;
+                    ++go;
+                }
+                ++gi;
+            }
+    }
+    __syncthreads();
+    const int P = n_partials(K, B);
+    double *out = a.partials + ((size_t)s * a.T + tile) * P;
+    for (int i = threadIdx.x; i < P - 1; i += SC_BLOCK) {
+        double r = 0;
+#pragma unroll
+        for (int w = 0; w < SC_NWAVES; ++w) r += red[w][i];
+        out[1 + i] = r;
+    }
+    if (threadIdx.x == 0) {
+        double l = 0;
+        if (tile == 0) for (int b = 0; b < B; ++b) l += a.loss_part[s * B + b];
+        out[0] = l;
+    }
+}
+
+// the morphology step of k_step_psf on compact planes, 16 B per lane; the scalar head (Lipschitz constants,
+// SED step) is shared through a device function
+template <int KM, int BM>
+__device__ __forceinline__ void step_psf_head(const PsfArgs &a, int s, int tile, double *tot, double *mat, float *sed_s,
+                                              float *step_s, double *Lc, double (*eigbuf)[2][64])
+{
+    const int K = a.K, B = a.B, P = n_partials(K, B);
+    for (int i = threadIdx.x; i < P; i += SC_BLOCK) {
+        double r = 0;
+        for (int t = 0; t < a.T; ++t) r += a.partials[((size_t)s * a.T + t) * P + i];
+        tot[i] = r;
+    }
+    const int c0 = a.cur[s];
+    const float *sed_in = a.sed[c0];
+    float *sed_out = a.sed[1 - c0];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
+        sed_s[(i / B) * BM + (i % B)] = sed_in[(size_t)s * K * B + i];
+    __syncthreads();
+    const int it_new = a.it[s] + 1;
+    if (a.approximate_L) {
+        if (threadIdx.x == 0) {
+            double LA = 0, LS = 0;
+            int go = 0;
+            for (int k = 0; k < K; ++k)
+                for (int k2 = k; k2 < K; ++k2) { if (k2 == k) LA += tot[1 + K * B + go]; ++go; }
+            for (int k = 0; k < K; ++k)
+                for (int b = 0; b < B; ++b) LS += (double)sed_s[k * BM + b] * sed_s[k * BM + b];
+            if (it_new > 1 && tot[0] > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { LA *= 2; LS *= 2; }
+            Lc[0] = LA; Lc[1] = LS;
+        }
+        __syncthreads();
+    } else {
+        double *G = mat, *ATA = mat + KM * KM;
+        for (int i = threadIdx.x; i < K * K; i += SC_BLOCK) {
+            const int k = i / K, k2 = i - k * K, lo = k < k2 ? k : k2, hi = k < k2 ? k2 : k;
+            G[k * KM + k2] = tot[1 + K * B + lo * K - (lo * (lo - 1)) / 2 + (hi - lo)];
+        }
+        for (int i = threadIdx.x; i < B * B; i += SC_BLOCK) {
+            const int b = i / B, b2 = i - b * B;
+            double r = 0;
+            for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
+            ATA[b * BM + b2] = r;
+        }
+        __syncthreads();
+        block_lipschitz(G, K, KM, ATA, B, BM, eigbuf, Lc);
+    }
+    if (threadIdx.x == 0) {
+        step_s[0] = 1.0f / (float)Lc[0];
+        step_s[1] = 1.0f / (float)Lc[1];
+        if (tile == 0) {
+            if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = tot[0];
+            a.lipschitz[2 * s] = Lc[0];
+            a.lipschitz[2 * s + 1] = Lc[1];
+        }
+    }
+    __syncthreads();
+    if (tile == 0)
+        for (int i = threadIdx.x; i < K * B; i += SC_BLOCK) {
+            const int k = i / B;
+            const float curv = sed_s[k * BM + (i % B)];
+            const bool fixed = a.fix_sed && a.fix_sed[(size_t)s * K + k];
+            sed_out[(size_t)s * K * B + i] = a.raw_gradient ? (float)tot[1 + i] : (fixed ? curv : curv - step_s[0] * (float)tot[1 + i]);
+        }
+}
+
+template <int KM, int BM>
+__global__ __launch_bounds__(SC_BLOCK) void k_step_psf4(PsfArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.g.H * a.g.W;
+    __shared__ double tot[1 + KM * BM + KM * (KM + 1) / 2];
+    __shared__ double mat[KM * KM + BM * BM];
+    __shared__ float sed_s[KM * BM];
+    __shared__ float step_s[2];
+    __shared__ double Lc[2];
+    __shared__ double eigbuf[2][2][64];
+    step_psf_head<KM, BM>(a, s, tile, tot, mat, sed_s, step_s, Lc, eigbuf);
+    const float step_morph = step_s[1];
+    const int c0 = a.cur[s], HW4 = HW >> 2;
+    const float4 *mor = reinterpret_cast<const float4 *>(a.morph[c0] + (size_t)s * K * HW);
+    float4 *mout = reinterpret_cast<float4 *>(a.morph[1 - c0] + (size_t)s * K * HW);
+    const float4 *G = reinterpret_cast<const float4 *>(a.real + (size_t)s * B * HW);
+    const int g_end = min(HW4, (tile + 1) * (SC_TILE_PIX >> 2));
+    for (int g = tile * (SC_TILE_PIX >> 2) + threadIdx.x; g < g_end; g += SC_BLOCK) {
+        float4 gb[BM];
+#pragma unroll
+        for (int b = 0; b < BM; ++b) gb[b] = b < B ? G[(size_t)b * HW4 + g] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < K) {
+                const float4 m = mor[(size_t)k * HW4 + g];
+                float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int b = 0; b < BM; ++b)
+                    if (b < B) {
+                        const float sk = sed_s[k * BM + b];
+                        gm.x += sk * gb[b].x; gm.y += sk * gb[b].y; gm.z += sk * gb[b].z; gm.w += sk * gb[b].w;
+                    }
+                const bool fixed = a.fix_morph && a.fix_morph[(size_t)s * K + k];
+                float4 o;
+                if (a.raw_gradient) o = gm;
+                else if (fixed) o = m;
+                else o = make_float4(m.x - step_morph * gm.x, m.y - step_morph * gm.y, m.z - step_morph * gm.z, m.w - step_morph * gm.w);
+                mout[(size_t)k * HW4 + g] = o;
+            }
+    }
+}
+
+// model planes, compact [S][B][H*W], 16 B per lane (k_psf_model with the geometry of an unpadded plane)
+__global__ __launch_bounds__(SC_BLOCK) void k_psf_model4(PsfArgs a)
+{
+    const int s = blockIdx.y;
+    if (!a.active[s]) return;
+    const int c0 = a.cur[s], HW4 = (a.g.H * a.g.W) >> 2, K = a.K, B = a.B;
+    __shared__ float sed_s[SC_KBIG * SC_BMAX];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
+        sed_s[(i / B) * SC_BMAX + (i % B)] = a.sed[c0][(size_t)s * K * B + i];
+    __syncthreads();
+    const int g = blockIdx.x * SC_BLOCK + threadIdx.x;
+    if (g >= HW4) return;
+    float4 v[SC_BMAX];
+#pragma unroll
+    for (int b = 0; b < SC_BMAX; ++b) v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 *mor = reinterpret_cast<const float4 *>(a.morph[c0] + (size_t)s * K * HW4 * 4) + g;
+    for (int k = 0; k < K; ++k) {
+        const float4 m = mor[(size_t)k * HW4];
+#pragma unroll
+        for (int b = 0; b < SC_BMAX; ++b)
+            if (b < B) {
+                const float sk = sed_s[k * SC_BMAX + b];
+                v[b].x += sk * m.x; v[b].y += sk * m.y; v[b].z += sk * m.z; v[b].w += sk * m.w;
+            }
+    }
+    float4 *out = reinterpret_cast<float4 *>(a.real + (size_t)s * B * HW4 * 4) + g;
+#pragma unroll
+    for (int b = 0; b < SC_BMAX; ++b)
+        if (b < B) out[(size_t)b * HW4] = v[b];
+}
+
 // kernel image [B][Py][Px] -> padded, shifted FFT input planes [B][Fy][Fx]
 __global__ void k_psf_pad_kernel(const float *ker, int B, int Py, int Px, int Fy, int Fx, int oky, int okx,
                                  float *out)

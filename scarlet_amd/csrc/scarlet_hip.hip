@@ -1032,7 +1032,10 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         prof_start(5, st);
         // model planes, compact [S][B][H][W], into `real` (k_psf_model with the geometry of an unpadded plane)
         a.g.Fy = b->H; a.g.Fx = b->W; a.g.Fxh = b->W / 2 + 1; a.g.oy = 0; a.g.ox = 0;
-        hipLaunchKernelGGL(k_psf_model, dim3((b->H * b->W + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
+        if ((b->H * b->W) % 4 == 0)
+            hipLaunchKernelGGL(k_psf_model4, dim3(((b->H * b->W) / 4 + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
+        else
+            hipLaunchKernelGGL(k_psf_model, dim3((b->H * b->W + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
         long long *stamps = opt(OPT_STAMPS) ? (long long *)((char *)b->workspace + l.stamps) : nullptr;
         fp.stagger_wgs = 0;
         hipLaunchKernelGGL(k_psf_conv, dim3(groups * 8 * b->B), dim3(SC_FFT_NT), lds, st, a, fp, a.real, stamps);
@@ -1077,7 +1080,16 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         HIP_TRY(hipGetLastError());
         return SCARLET_OK;
     }
-    if (b->K <= 4) {
+    if (lds_path && (b->H * b->W) % 4 == 0) {
+        // compact gradient planes: 16 B per lane
+        prof_start(0, st);
+        if (b->K <= 4) hipLaunchKernelGGL((k_grad_psf4<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((k_grad_psf4<SC_KMAX, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_stop(st); prof_start(1, st);
+        if (b->K <= 4) hipLaunchKernelGGL((k_step_psf4<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((k_step_psf4<SC_KMAX, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+        prof_stop(st);
+    } else if (b->K <= 4) {
         prof_start(0, st);
         hipLaunchKernelGGL((k_grad_psf<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
         prof_stop(st); prof_start(1, st);
@@ -1256,10 +1268,14 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
         // frames beyond the wave-level tile: the pipeline on the box around each peak (boxupdate.h); the kernels
         // below then run only for the components whose footprint left the box
         const size_t ldsb = sizeof(float) * ub_lds_floats(b->H, b->W);
-        rc = allow_lds(k_source_update_box, ldsb);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_source_update_box, dim3(b->S * b->K), dim3(SC_BLOCK), ldsb, (hipStream_t)stream, u, ws_box_fallback(b),
-                           debug_stamps((size_t)b->S * b->K * 16));
+        long long *dbg = debug_stamps((size_t)b->S * b->K * 16);
+        if (b->H <= 128) {
+            if ((rc = allow_lds(k_source_update_box<8>, ldsb))) return rc;
+            hipLaunchKernelGGL(k_source_update_box<8>, dim3(b->S * b->K), dim3(SC_BLOCK), ldsb, (hipStream_t)stream, u, ws_box_fallback(b), dbg);
+        } else {
+            if ((rc = allow_lds(k_source_update_box<16>, ldsb))) return rc;
+            hipLaunchKernelGGL(k_source_update_box<16>, dim3(b->S * b->K), dim3(SC_BLOCK), ldsb, (hipStream_t)stream, u, ws_box_fallback(b), dbg);
+        }
         u.only_flagged = ws_box_fallback(b);
     }
     if (b->H <= 64 && b->W <= 64 && !opt(OPT_FORCE_BLOCK_UPDATE)) {
