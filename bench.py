@@ -45,15 +45,15 @@ CLASS_NAMES = ("k_grad", "k_step", "k_source_update", "k_converge", "k_iterate",
 CONFIGS = {
     # scenes per GPU, bands, size, sources, psf, l0, min_sep, first scene index, distinct scenes generated
     "c2": dict(S=10000, B=5, H=64, W=64, K=4, psf=False, l0=None, min_sep=4, first=0, unique=None,
-               cpu_scenes=24, cpu_iters=50,
+               cpu_scenes=96, cpu_iters=50,
                label="%d scenes/GPU of 5-band 64x64, 4 sources/scene, no PSF (BASELINE configs[3] shape; "
                      "configs[1] is the same at batch 1024)"),
     "c3": dict(S=4096, B=5, H=128, W=128, K=8, psf=True, l0=None, min_sep=4, first=300, unique=64,
-               cpu_scenes=1, cpu_iters=10,
+               cpu_scenes=8, cpu_iters=25,
                label="%d scenes/GPU of 5-band 128x128, 8 sources/scene, per-band 41x41 PSF, FFT-convolution "
                      "render (BASELINE configs[2])"),
     "c5": dict(S=64, B=6, H=256, W=256, K=30, psf=False, l0=0.05, min_sep=3, first=5000, unique=8,
-               cpu_scenes=1, cpu_iters=2,
+               cpu_scenes=4, cpu_iters=10,
                label="%d scenes/GPU of 6-band 256x256, 30 overlapping sources/scene, symmetry + monotonicity + "
                      "L0 (BASELINE configs[4]: 512 scenes over 8 GPUs)"),
 }
