@@ -244,6 +244,13 @@ typedef struct scarlet_batch {
     /* workspace owned by the caller: scarlet_batch_workspace_bytes() bytes, ZEROED before
        the first call (it also holds a cache keyed by a magic word)                     */
     void *workspace;
+    /* MultiComponentSource (source.py:538-641): [S][K] device int32 or NULL.  -1: the component is a
+       source of its own (PointSource / ExtendedSource.update, source.py:402-440); g >= 0: it is a layer of
+       multi-component source g of its scene -- the layers of a source share ONE centre, measured on their
+       flux-weighted sum (max_pixel, and psf_weighted_centroid every fifth iteration, source.py:613-630),
+       and are symmetrised about it with shift = None (update.symmetric falls back to soft symmetry,
+       operator.py:337-339).  The members of a source must be adjacent components.             */
+    const int32_t *group;
 } scarlet_batch;
 
 /* bytes of device workspace needed for `b` (depends on S, K, B, H, W only) */

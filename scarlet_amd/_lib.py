@@ -50,6 +50,7 @@ class ScarletBatch(Structure):
         ("diff_kernel", c_void_p), ("psf_h", c_int32), ("psf_w", c_int32),
         ("diff_kernel_per_scene", c_int32),
         ("workspace", c_void_p),
+        ("group", c_void_p),
     ]
 
 

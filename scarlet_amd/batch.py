@@ -31,11 +31,14 @@ class BlendBatch(object):
     symmetric, monotonic : constraint switches of PointSource/ExtendedSource.update
     l0_thresh, l1_thresh : None or sparsity thresholds (update.sparse_l0 / sparse_l1)
     centroid_weight : (P, P) float64 centroid PSF; default = reference default
+    group : None, or (S, K) integers: -1 = the component is a source of its own, g >= 0 = it is a layer of
+        multi-component source g of its scene (reference MultiComponentSource, source.py:538-641): the layers
+        of a source (adjacent components) share one centre measured on their flux-weighted sum
     """
 
     def __init__(self, images, centers, weights=None, symmetric=True, monotonic=True,
                  l0_thresh=None, l1_thresh=None, centroid_weight=None, mse_capacity=256,
-                 device=None):
+                 device=None, group=None):
         torch = _lib.require_gpu()
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -67,6 +70,16 @@ class BlendBatch(object):
         self.status = torch.zeros((S,), **i32)
         self.fix_sed = None
         self.fix_morph = None
+        self.group = None
+        if group is not None:
+            g = np.asarray(group, dtype=np.int32).reshape(S, K)
+            for row in g:                    # the layers of a source are adjacent components
+                seen = set()
+                for k, v in enumerate(row):
+                    if v >= 0 and v in seen and row[k - 1] != v:
+                        raise ValueError("the components of a multi-component source must be adjacent")
+                    seen.add(int(v))
+            self.group = torch.as_tensor(g).to(**i32).contiguous()
         self.symmetric, self.monotonic = bool(symmetric), bool(monotonic)
         self.l0_thresh, self.l1_thresh = l0_thresh, l1_thresh
         cw = default_centroid_weight() if centroid_weight is None else np.asarray(centroid_weight, dtype=np.float64)
@@ -104,6 +117,7 @@ class BlendBatch(object):
         c.l0_thresh = -1.0 if self.l0_thresh is None else float(self.l0_thresh)
         c.l1_thresh = -1.0 if self.l1_thresh is None else float(self.l1_thresh)
         c.centroid_psf, c.centroid_P = p(self.centroid_weight), int(self.centroid_weight.shape[0])
+        c.group = p(self.group)
         if getattr(self, "workspace", None) is not None:
             c.workspace = self.workspace.data_ptr()
 

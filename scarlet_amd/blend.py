@@ -55,8 +55,17 @@ class Blend(ComponentTree):
 
     def _builtin_pipeline(self):
         """True when every source uses the reference's stock update() (source.py:402-440)."""
-        from .source import PointSource
+        from .source import PointSource, MultiComponentSource
+        if getattr(self, "python_pipeline", False):        # tests: force the per-source Python update() path
+            return False
         for s in self.sources:
+            if isinstance(s, MultiComponentSource):
+                # layered sources: shared centre on the device (k_group_centers), stock update only
+                if type(s).update is not MultiComponentSource.update or hasattr(s, "bboxes"):
+                    return False
+                if any(c.prior is not None for c in s.components):
+                    return False
+                continue
             if not isinstance(s, PointSource) or type(s).update is not PointSource.update:
                 return False
             if getattr(s, "prior", None) is not None or hasattr(s, "bboxes"):
@@ -75,12 +84,19 @@ class Blend(ComponentTree):
         multi = len(self.observations) != 1 or self.observations[0]._band_slice != slice(None)
         obs = self.observations[0]
         comps = self.components
-        centers = []
-        for c in comps:
-            pc = getattr(c, "pixel_center", None)
-            if pc is None:
-                pc = (self.frame.Ny // 2, self.frame.Nx // 2)
-            centers.append((int(pc[0]), int(pc[1])))
+        from .source import MultiComponentSource
+        centers, group, owner = [], [], []
+        for si, src in enumerate(self.sources):
+            layered = isinstance(src, MultiComponentSource)
+            for c in (src.components if hasattr(src, "components") else [src]):
+                pc = getattr(src if layered else c, "pixel_center", None)
+                if pc is None:
+                    pc = (self.frame.Ny // 2, self.frame.Nx // 2)
+                centers.append((int(pc[0]), int(pc[1])))
+                group.append(si if layered else -1)
+                owner.append(src if layered else None)
+        assert len(centers) == len(comps)
+        self._group_owner = owner
         cw = None
         for s in self.sources:
             if getattr(s, "_centroid_weight", None) is not None:
@@ -94,7 +110,8 @@ class Blend(ComponentTree):
                             weights=None if (images is not None or o._weights_device() is None) else o._weights_device()[None],
                             symmetric=bool(self.sources[0].symmetric) if builtin else False,
                             monotonic=bool(self.sources[0].monotonic) if builtin else False,
-                            centroid_weight=cw)
+                            centroid_weight=cw,
+                            group=np.array(group, dtype=np.int32)[None] if (builtin and any(g >= 0 for g in group)) else None)
             if images is None:
                 if type(o.weights) is not np.ndarray and o.weights != 1:
                     ob.weight_scalar = float(o.weights)
@@ -146,7 +163,12 @@ class Blend(ComponentTree):
         self.L_sed, self.L_morph = float(L[0]), float(L[1])
         for k, c in enumerate(self.components):
             c.L_sed, c.L_morph = self.L_sed, self.L_morph
-            if hasattr(c, "pixel_center"):
+            tgt = c if hasattr(c, "pixel_center") else getattr(self, "_group_owner", [None] * (k + 1))[k]
+            if tgt is not None and self._builtin_pipeline():
+                tgt.pixel_center = (int(cen[k, 0]), int(cen[k, 1]))
+                if not np.isnan(sh[k, 0]):
+                    tgt.shift = (float(sh[k, 0]), float(sh[k, 1]))
+            elif hasattr(c, "pixel_center"):
                 c.pixel_center = (int(cen[k, 0]), int(cen[k, 1]))
                 if not np.isnan(sh[k, 0]):
                     c.shift = (float(sh[k, 0]), float(sh[k, 1]))

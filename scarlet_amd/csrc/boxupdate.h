@@ -72,16 +72,19 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a,
     __syncthreads();
     const int it = a.force_it0 ? 0 : a.it[s] + (a.in_iteration ? 1 : 0);
     int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
-    if (threadIdx.x < SC_WAVE) {                                             // source.py:414 (25 lanes, one load each)
-        int st = 0;
-        wave_max_pixel(tg, cy, cx, st);
-        if (threadIdx.x == 0) { ctr[0] = cy; ctr[1] = cx; if (st) stat |= st; }
+    const bool grouped = a.group && a.group[c] >= 0;      // layer of a MultiComponentSource: centre from k_group_centers, shift = None
+    if (!grouped) {
+        if (threadIdx.x < SC_WAVE) {                                         // source.py:414 (25 lanes, one load each)
+            int st = 0;
+            wave_max_pixel(tg, cy, cx, st);
+            if (threadIdx.x == 0) { ctr[0] = cy; ctr[1] = cx; if (st) stat |= st; }
+        }
+        __syncthreads();
+        cy = ctr[0]; cx = ctr[1];
     }
-    __syncthreads();
-    cy = ctr[0]; cx = ctr[1];
-    double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
+    double dy = grouped ? (double)__builtin_nanf("") : a.shifts[2 * c], dx = grouped ? dy : a.shifts[2 * c + 1];
     bool new_shift = false;
-    if (a.symmetric && it % 5 == 0) {                                        // source.py:428-429
+    if (!grouped && a.symmetric && it % 5 == 0) {                            // source.py:428-429
         __syncthreads();
         centroid_tile(tg, a.centroid_psf, a.centroid_P, cy, cx, red, ctr, shf, &stat);
         cy = ctr[0]; cx = ctr[1]; dy = shf[0]; dx = shf[1];

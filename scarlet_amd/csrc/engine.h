@@ -475,6 +475,8 @@ struct UpdateArgs {
     float *gscratch;                  // GT kernels: [S*K][round16(H) * scratch_stride(round16(W))] (T = X B)
     int hybrid_sweep;                 // LDS tiles: sweep levels 1 .. 46 on one wave (wave_monotonic), the rest on the workgroup
     const int *only_flagged;          // [S*K] or NULL: run only for the components k_source_update_box left to the full path
+    const int *group;                 // [S*K] or NULL: >= 0 = layer of a multi-component source: centre given (k_group_centers),
+                                      // shift = None (soft symmetry); -1 = a source of its own
 };
 
 // MODE 0/1: the morphology tile lives in LDS (tiles up to ~128 x 128).
@@ -548,12 +550,15 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
     __syncthreads();
     const int it = a.force_it0 ? 0 : a.it[s] + (a.in_iteration ? 1 : 0);   // len(mse)
     int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
+    const bool grouped = a.group && a.group[c] >= 0;               // layer of a MultiComponentSource: centre from k_group_centers
 
-    max_pixel_tile(t, cy, cx, ctr, &stat);                         // source.py:414
-    cy = ctr[0]; cx = ctr[1];
+    if (!grouped) {
+        max_pixel_tile(t, cy, cx, ctr, &stat);                     // source.py:414
+        cy = ctr[0]; cx = ctr[1];
+    }
     if (a.symmetric) {
-        double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
-        if (it % 5 == 0) {                                          // source.py:428-429
+        double dy = grouped ? (double)__builtin_nanf("") : a.shifts[2 * c], dx = grouped ? dy : a.shifts[2 * c + 1];
+        if (!grouped && it % 5 == 0) {                              // source.py:428-429
             __syncthreads();
             centroid_tile(t, a.centroid_psf, a.centroid_P, cy, cx, red, ctr, shf, &stat);
             cy = ctr[0]; cx = ctr[1]; dy = shf[0]; dx = shf[1];
@@ -708,6 +713,63 @@ __global__ __launch_bounds__(SC_BLOCK) void k_source_update(UpdateArgs a)
 }
 
 // ------------------------------------------------------------------------------------
+// k_group_centers: the shared centre of every MultiComponentSource (source.py:613-630), one wave per scene.
+// For each source g: _morph = sum over its layers of morph_c * sed_c.sum() (float32, layer by layer, as
+// np.sum over the list does), max_pixel around the previous centre, and on every fifth iteration the
+// PSF-weighted centroid.  _morph is materialised only on the patch both windows can touch (the centroid's radius
+// + 2 around the previous centre, clipped to the frame: inside it every bounds decision equals the frame's).
+// The new centre (and shift) is written to EVERY layer of the source; the update kernels take it as given.
+__global__ __launch_bounds__(SC_WAVE) void k_group_centers(UpdateArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    const int s = blockIdx.x;
+    if (!a.force_it0 && !a.active[s]) return;
+    const int K = a.K, B = a.B, H = a.H, W = a.W, HW = H * W, lane = threadIdx.x;
+    const int c0 = a.cur[s], wbuf = a.in_iteration ? 1 - c0 : c0;
+    const int it = a.force_it0 ? 0 : a.it[s] + (a.in_iteration ? 1 : 0);
+    const int R = a.centroid_P / 2 + 2, PW = 2 * R + 1 + 1;                      // patch radius, LDS row stride
+    for (int k0 = 0; k0 < K; ++k0) {
+        const int g = a.group[s * K + k0];
+        if (g < 0 || (k0 > 0 && a.group[s * K + k0 - 1] == g)) continue;          // not a layer / not the first layer of its source
+        int k1 = k0 + 1;
+        while (k1 < K && a.group[s * K + k1] == g) ++k1;
+        int cy = a.centers[2 * (s * K + k0)], cx = a.centers[2 * (s * K + k0) + 1];
+        const int py0 = max(0, cy - R), px0 = max(0, cx - R);
+        const int ph = min(H, cy + R + 1) - py0, pw = min(W, cx + R + 1) - px0;
+        for (int i = lane; i < ph * pw; i += SC_WAVE) {
+            const int y = i / pw, x = i - y * pw;
+            float acc = 0.f;
+            for (int k = k0; k < k1; ++k) {
+                const float *sed = a.sed[wbuf] + (size_t)(s * K + k) * B;
+                float ssum = 0.f;
+                for (int b = 0; b < B; ++b) ssum += sed[b];
+                acc += a.morph[wbuf][(size_t)(s * K + k) * HW + (py0 + y) * W + px0 + x] * ssum;
+            }
+            lds[y * PW + x] = acc;
+        }
+        wave_sync();
+        Tile t; t.H = ph; t.W = pw; t.LW = PW; t.m = lds;
+        int stat = 0, ly = cy - py0, lx = cx - px0;
+        wave_max_pixel(t, ly, lx, stat);
+        double dy = a.shifts[2 * (s * K + k0)], dx = a.shifts[2 * (s * K + k0) + 1];
+        bool new_shift = false;
+        if (a.symmetric && it % 5 == 0) {
+            wave_centroid(t, a.centroid_psf, a.centroid_P, ly, lx, dy, dx, stat);
+            new_shift = true;
+        }
+        cy = ly + py0; cx = lx + px0;
+        if (lane == 0) {
+            for (int k = k0; k < k1; ++k) {
+                a.centers[2 * (s * K + k)] = cy; a.centers[2 * (s * K + k) + 1] = cx;
+                if (new_shift) { a.shifts[2 * (s * K + k)] = dy; a.shifts[2 * (s * K + k) + 1] = dx; }
+            }
+            if (stat) atomicOr(&a.status[s], stat);
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_converge: Blend._check_convergence (blend.py:141-184), one thread per scene.
 // Also closes the iteration for the scene: it += 1 (len(mse)), cur flips.
 __global__ void k_converge(int S, int K, const double *conv, int *flags, int *active,
@@ -763,10 +825,11 @@ __device__ inline void wave_pipeline(const UpdateArgs &a, int c, float *lds_wave
     const int it = a.force_it0 ? 0 : a.it[s] + (a.in_iteration ? 1 : 0);
     int cy = a.centers[2 * c], cx = a.centers[2 * c + 1];
     int stat = 0;
-    wave_max_pixel(t, cy, cx, stat);
+    const bool grouped = a.group && a.group[c] >= 0;               // layer of a MultiComponentSource: centre from k_group_centers
+    if (!grouped) wave_max_pixel(t, cy, cx, stat);
     if (a.symmetric) {
-        double dy = a.shifts[2 * c], dx = a.shifts[2 * c + 1];
-        if (it % 5 == 0) {
+        double dy = grouped ? (double)__builtin_nanf("") : a.shifts[2 * c], dx = grouped ? dy : a.shifts[2 * c + 1];
+        if (!grouped && it % 5 == 0) {
             wave_centroid(t, a.centroid_psf, a.centroid_P, cy, cx, dy, dx, stat);
             if (lane == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
         }

@@ -1262,6 +1262,14 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
     u.centroid_psf = b->centroid_psf; u.centroid_P = b->centroid_P; u.conv = ws_conv(b); u.force_it0 = force_it0;
     u.gscratch = nullptr;
     u.only_flagged = nullptr;
+    u.group = b->group;
+    if (b->group) {
+        // MultiComponentSource: the shared centre of every source first (one wave per scene)
+        const int R = b->centroid_P / 2 + 2;
+        const size_t ldsg = sizeof(float) * (size_t)(2 * R + 1) * (2 * R + 2);
+        if ((rc = allow_lds(k_group_centers, ldsg))) return rc;
+        hipLaunchKernelGGL(k_group_centers, dim3(b->S), dim3(SC_WAVE), ldsg, (hipStream_t)stream, u);
+    }
     u.hybrid_sweep = opt(OPT_NO_HYBRID_SWEEP) ? 0 : 1;
     if ((b->H > 64 || b->W > 64) && b->H <= 256 && b->W <= 256 && b->monotonic && !opt(OPT_NO_BOX) &&
         sizeof(float) * ub_lds_floats(b->H, b->W) <= LDS_LIMIT) {
@@ -1339,7 +1347,7 @@ static bool fused_ok(const scarlet_batch *b, int approximate_L)
 {
     // K > 4: eight tiles leave one workgroup per CU and the general path is faster (measured at K = 6, 8:
     // 2.44 vs 2.58 ms and 3.25 vs 3.90 ms per iteration of 4000 scenes)
-    if (approximate_L || b->diff_kernel || b->K > 4 || opt(OPT_NO_FUSED)) return false;
+    if (approximate_L || b->diff_kernel || b->K > 4 || b->group || opt(OPT_NO_FUSED)) return false;
     if (b->H > 64 || b->W > 64 || (b->W & 3) || b->H < 3 || b->W < 3) return false;
     return fused_lds_bytes(b) <= LDS_LIMIT - 4096;
 }

@@ -324,7 +324,9 @@ def test_prior_hooks_match_the_oracle(scarlet):
 def test_multicomponent_source_matches_the_oracle(scarlet):
     """MultiComponentSource (reference source.py:242-295, 495-641): layered initialisation, shared
     centre measured on the flux-weighted sum, per-component constraints.  One two-component source
-    + two extended sources, 8 iterations through the Python pipeline, against the CPU oracle."""
+    + two extended sources, 8 iterations -- through the DEVICE pipeline (scarlet_fit with the `group` field:
+    k_group_centers + the grouped mode of the update kernels, no host synchronisation per iteration) and
+    through the Python pipeline (per-source update()), both against the CPU oracle and the reference's fixture."""
     from oracle import pgm
     from scarlet_amd import synth
     scn = synth.make_scene(5)
@@ -346,7 +348,12 @@ def test_multicomponent_source_matches_the_oracle(scarlet):
     others = [scarlet.ExtendedSource(frame, p, obs, bg) for p in cen[1:3]]
     blend = scarlet.Blend([multi] + others, obs)
     comps = blend.components
-    assert len(comps) == 4 and not blend._builtin_pipeline()
+    assert len(comps) == 4 and blend._builtin_pipeline()
+    # the same blend through the Python pipeline (fresh sources: a Blend adopts its components)
+    multi_p = scarlet.MultiComponentSource(frame, cen[0], obs, bg, flux_percentiles=[30])
+    blend_p = scarlet.Blend([multi_p] + [scarlet.ExtendedSource(frame, p, obs, bg) for p in cen[1:3]], obs)
+    blend_p.python_pipeline = True
+    assert not blend_p._builtin_pipeline()
     osrc = []
     for s in others:
         o = pgm.Source(npy(s.sed), npy(s.morph), s.pixel_center, images.dtype,
@@ -356,16 +363,24 @@ def test_multicomponent_source_matches_the_oracle(scarlet):
     sc = pgm.Scene(images, oms.components + osrc)
     sc.trees = [oms] + osrc
     blend.fit(8, e_rel=0)
+    blend_p.fit(8, e_rel=0)
     pgm.fit(sc, 8, e_rel=0)
-    assert rel_err(blend.mse, sc.mse) < 1e-5
-    assert rel_err(np.array([npy(c.morph) for c in comps]), np.array([s.morph for s in sc.sources])) < 1e-5
-    assert rel_err(np.array([npy(c.sed) for c in comps]), np.array([s.sed for s in sc.sources])) < 1e-5
-    assert tuple(multi.pixel_center) == oms.center
     g = load_golden("fit_extras")                        # produced by the reference itself
-    assert rel_err(blend.mse, g["multi_mse"]) < 1e-5
-    assert rel_err(np.array([npy(c.morph) for c in comps]), g["multi_morph"]) < 1e-5
-    assert rel_err(np.array([npy(c.sed) for c in comps]), g["multi_sed"]) < 1e-5
-    assert_array_equal(np.array(multi.pixel_center), g["multi_center"])
+    for bl, mu in ((blend, multi), (blend_p, multi_p)):
+        cs = bl.components
+        assert rel_err(bl.mse, sc.mse) < 1e-5
+        assert rel_err(np.array([npy(c.morph) for c in cs]), np.array([s.morph for s in sc.sources])) < 1e-5
+        assert rel_err(np.array([npy(c.sed) for c in cs]), np.array([s.sed for s in sc.sources])) < 1e-5
+        assert tuple(mu.pixel_center) == oms.center
+        assert rel_err(bl.mse, g["multi_mse"]) < 1e-5
+        assert rel_err(np.array([npy(c.morph) for c in cs]), g["multi_morph"]) < 1e-5
+        assert rel_err(np.array([npy(c.sed) for c in cs]), g["multi_sed"]) < 1e-5
+        assert_array_equal(np.array(mu.pixel_center), g["multi_center"])
+    # a longer run across two centroid iterations (it % 5 == 0), the pipelines against each other
+    blend.fit(7, e_rel=0); blend_p.fit(7, e_rel=0)
+    assert rel_err(np.array([npy(c.morph) for c in blend.components]), np.array([npy(c.morph) for c in blend_p.components])) < 1e-5
+    assert tuple(multi.pixel_center) == tuple(multi_p.pixel_center)
+    assert np.allclose(multi.shift, multi_p.shift, atol=1e-6)
 
 
 def test_several_observations_match_the_reference(scarlet):
@@ -637,3 +652,27 @@ def test_two_host_threads_on_two_streams(scarlet):
     assert not errs, errs
     np.testing.assert_array_equal(got["a"], ref["a"])
     np.testing.assert_array_equal(got["b"], ref["b"])
+
+
+def test_multicomponent_device_pipeline_on_a_large_frame(scarlet):
+    """the grouped mode of the box kernel (frames > 64: k_source_update_box) against the Python pipeline and the oracle"""
+    from oracle import pgm
+    from scarlet_amd import synth
+    scn = synth.make_scene(77, H=96, W=80, K=3)
+    images = scn["images"]
+    frame = scarlet.Frame(images.shape)
+    obs = scarlet.Observation(images).match(frame)
+    bg = np.ones(5) * 0.1
+    cen = [tuple(int(v) for v in p) for p in scn["centers"]]
+    def make(py):
+        m = scarlet.MultiComponentSource(frame, cen[0], obs, bg, flux_percentiles=[30])
+        bl = scarlet.Blend([scarlet.ExtendedSource(frame, cen[1], obs, bg), m], obs)
+        bl.python_pipeline = py
+        return bl, m
+    (bd, md), (bp, mp) = make(False), make(True)
+    assert bd._builtin_pipeline() and not bp._builtin_pipeline()
+    bd.fit(11, e_rel=0); bp.fit(11, e_rel=0)
+    assert rel_err(bd.mse, bp.mse) < 1e-5
+    assert rel_err(np.array([npy(c.morph) for c in bd.components]), np.array([npy(c.morph) for c in bp.components])) < 1e-5
+    assert rel_err(np.array([npy(c.sed) for c in bd.components]), np.array([npy(c.sed) for c in bp.components])) < 1e-5
+    assert tuple(md.pixel_center) == tuple(mp.pixel_center)
