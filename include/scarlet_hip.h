@@ -268,6 +268,16 @@ int64_t scarlet_batch_workspace_bytes(const scarlet_batch *b);
 int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int approximate_L,
                 int check_every, void *stream);
 
+/* Blend.fit with SEVERAL observations (blend.py:24-43, 120-139, 219-220), no host synchronisation per
+ * iteration.  `state` holds the factors over the model frame's C = state->B channels (its `images` are not
+ * read: pass any buffer of the right size); obs[i] (n_obs <= 8) is a batch over the channels band0[i] ..
+ * band0[i] + obs[i]->B - 1 with its own images / weights / PSF kernel / workspace and the same S, K, H, W --
+ * its factor buffers are scratch of this call.  Per iteration: every observation's loss gradient
+ * (scarlet_backward_gradients), their sum, L * n_obs (exact or approximate), the step, the constraint
+ * pipeline and the convergence test on `state`.  Returns the number of iterations launched. */
+int scarlet_fit_multi(scarlet_batch *state, scarlet_batch *const *obs, const int32_t *band0, int n_obs,
+                      int max_iter, double e_rel, int approximate_L, int check_every, void *stream);
+
 /* Single phases, exposed for tests and for Python-overridden update() methods:        */
 /* _backward + _set_lipschitz + gradient step (blend.py:81-96): reads buffer cur, writes
  * the stepped factors into buffer 1-cur; cur/it are NOT advanced yet                   */

@@ -70,8 +70,6 @@ class Blend(ComponentTree):
                 return False
             if getattr(s, "prior", None) is not None or hasattr(s, "bboxes"):
                 return False
-        if len(self.observations) != 1 or self.observations[0]._band_slice != slice(None):
-            return False
         sym = {bool(s.symmetric) for s in self.sources}
         mono = {bool(s.monotonic) for s in self.sources}
         return len(sym) == 1 and len(mono) == 1
@@ -198,7 +196,19 @@ class Blend(ComponentTree):
         """Fit the model of every source to the data (reference blend.py:65-102)."""
         b = self._ensure_batch()
         if self._builtin_pipeline():
-            b.fit(max_iter, e_rel=e_rel, approximate_L=approximate_L, check_every=4)
+            if self._obs_batches is None:
+                b.fit(max_iter, e_rel=e_rel, approximate_L=approximate_L, check_every=4)
+            else:
+                # several observations / band slices (reference blend.py:120-139, 219-220): gradients of every
+                # observation, their sum, L * n_obs, step, constraints and convergence in one device loop
+                b._ensure_mse_capacity(max_iter)
+                b.active.fill_(1)
+                n = len(self._obs_batches)
+                ptrs = (ctypes.POINTER(_lib.ScarletBatch) * n)(*[ctypes.pointer(ob._c) for ob, _ in self._obs_batches])
+                band0 = np.array([(sl.start or 0) for _, sl in self._obs_batches], dtype=np.int32)
+                _lib.check(_lib.lib.scarlet_fit_multi(ctypes.byref(b._c), ptrs, band0.ctypes.data_as(ctypes.c_void_p), n,
+                                                      int(max_iter), float(e_rel), int(bool(approximate_L)), 4,
+                                                      _lib.stream_ptr()))
             b.raise_on_status()
             self._sync_sources()
             return self

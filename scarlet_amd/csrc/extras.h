@@ -127,3 +127,102 @@ __global__ __launch_bounds__(SC_BLOCK) void k_resample(const float *in, float *o
         q[i] = (float)acc;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Several observations per blend (blend.py:24-43, 120-139, 219-220) on the device.  The factors live in a
+// STATE batch over the model frame's C channels; observation i is a batch over the channels band0[i] ..
+// band0[i] + B_i - 1 with its own images / weights / PSF kernel, used for gradients only.
+struct MultiObs {
+    float *sed[2], *morph[2];       // the observation batch's buffers: [0] receives the factors, [1] returns the gradients
+    int *cur, *it, *active;
+    const double *mse;              // [S][capacity]: slot 0 = the loss of this observation
+    int mse_capacity;
+    int B, band0;
+};
+#define SC_MULTI_MAX 8
+struct MultiArgs {
+    int S, K, C, HW, n_obs;
+    float *sed[2], *morph[2];       // state
+    const int *cur, *active;
+    int *it;
+    double *lipschitz, *mse;
+    int mse_capacity;
+    const uint8_t *fix_sed, *fix_morph;
+    int approximate_L;
+    MultiObs obs[SC_MULTI_MAX];
+};
+// factors of the current buffer -> every observation's buffer 0 (its band slice of the SEDs, the morphologies)
+__global__ __launch_bounds__(SC_BLOCK) void k_multi_scatter(MultiArgs a)
+{
+    const int c = blockIdx.y, s = c / a.K;                  // component
+    if (!a.active[s]) return;
+    const int c0 = a.cur[s];
+    const float *m = a.morph[c0] + (size_t)c * a.HW;
+    for (int o = 0; o < a.n_obs; ++o) {
+        float *dst = a.obs[o].morph[0] + (size_t)c * a.HW;
+        for (int i = blockIdx.x * SC_BLOCK + threadIdx.x; i < a.HW; i += gridDim.x * SC_BLOCK) dst[i] = m[i];
+        if (blockIdx.x == 0) {
+            if (threadIdx.x < a.obs[o].B)
+                a.obs[o].sed[0][(size_t)c * a.obs[o].B + threadIdx.x] = a.sed[c0][(size_t)c * a.C + a.obs[o].band0 + threadIdx.x];
+            if (threadIdx.x == 0 && c == s * a.K) { a.obs[o].cur[s] = 0; a.obs[o].it[s] = 0; a.obs[o].active[s] = 1; }
+        }
+    }
+}
+// loss = sum of the observations' losses; Lipschitz constants * n_obs (blend.py:219-220; approximate form:
+// blend.py:189-201 on the summed loss); one thread per scene
+__global__ void k_multi_loss(MultiArgs a, const double *approx_sums)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.S || !a.active[s]) return;
+    double loss = 0;
+    for (int o = 0; o < a.n_obs; ++o) loss += a.obs[o].mse[(size_t)s * a.obs[o].mse_capacity];
+    const int it_new = a.it[s] + 1;
+    if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
+    double Ls = a.lipschitz[2 * s], Lm = a.lipschitz[2 * s + 1];
+    if (a.approximate_L) {
+        Ls = approx_sums[2 * s]; Lm = approx_sums[2 * s + 1];       // sum |morph|^2, sum |sed|^2
+        if (it_new > 1 && loss > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { Ls *= 2; Lm *= 2; }
+    }
+    a.lipschitz[2 * s] = Ls * a.n_obs;
+    a.lipschitz[2 * s + 1] = Lm * a.n_obs;
+}
+// sum |morph|^2 and sum |sed|^2 of the current factors of a scene (approximate_L), one workgroup per scene
+__global__ __launch_bounds__(SC_BLOCK) void k_multi_approx(MultiArgs a, double *out)
+{
+    __shared__ double red[SC_NWAVES];
+    const int s = blockIdx.x;
+    if (!a.active[s]) return;
+    const int c0 = a.cur[s];
+    const float *m = a.morph[c0] + (size_t)s * a.K * a.HW, *sd = a.sed[c0] + (size_t)s * a.K * a.C;
+    double am = 0, as = 0;
+    for (int i = threadIdx.x; i < a.K * a.HW; i += SC_BLOCK) am += (double)m[i] * m[i];
+    for (int i = threadIdx.x; i < a.K * a.C; i += SC_BLOCK) as += (double)sd[i] * sd[i];
+    am = block_sum(am, red); as = block_sum(as, red);
+    if (threadIdx.x == 0) { out[2 * s] = am; out[2 * s + 1] = as; }
+}
+// gradients summed over the observations, step x - g / L into buffer 1 - cur (blend.py:87-96)
+__global__ __launch_bounds__(SC_BLOCK) void k_multi_step(MultiArgs a)
+{
+    const int c = blockIdx.y, s = c / a.K;
+    if (!a.active[s]) return;
+    const int c0 = a.cur[s];
+    const float step_sed = 1.0f / (float)a.lipschitz[2 * s], step_morph = 1.0f / (float)a.lipschitz[2 * s + 1];
+    const bool fixm = a.fix_morph && a.fix_morph[c], fixs = a.fix_sed && a.fix_sed[c];
+    const float *m = a.morph[c0] + (size_t)c * a.HW;
+    float *mo = a.morph[1 - c0] + (size_t)c * a.HW;
+    for (int i = blockIdx.x * SC_BLOCK + threadIdx.x; i < a.HW; i += gridDim.x * SC_BLOCK) {
+        float g = 0.f;
+        for (int o = 0; o < a.n_obs; ++o) g += a.obs[o].morph[1][(size_t)c * a.HW + i];
+        mo[i] = fixm ? m[i] : m[i] - step_morph * g;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < a.C) {
+        const int ch = threadIdx.x;
+        float g = 0.f;
+        for (int o = 0; o < a.n_obs; ++o) {
+            const int b = ch - a.obs[o].band0;
+            if (b >= 0 && b < a.obs[o].B) g += a.obs[o].sed[1][(size_t)c * a.obs[o].B + b];
+        }
+        const float x = a.sed[c0][(size_t)c * a.C + ch];
+        a.sed[1 - c0][(size_t)c * a.C + ch] = fixs ? x : x - step_sed * g;
+    }
+}

@@ -1460,6 +1460,61 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
     return launched;
 }
 
+// ---- several observations per blend (extras.h: MultiArgs)
+extern "C" int scarlet_fit_multi(scarlet_batch *state, scarlet_batch *const *obs, const int32_t *band0, int n_obs,
+                                 int max_iter, double e_rel, int approximate_L, int check_every, void *stream)
+{
+    int rc = check_batch(state);
+    if (rc) return rc;
+    if (!obs || !band0 || n_obs < 1 || n_obs > SC_MULTI_MAX) return set_err(SCARLET_E_ARG, "1 to 8 observations");
+    if (max_iter < 0) return set_err(SCARLET_E_ARG, "max_iter < 0");
+    MultiArgs m;
+    m.S = state->S; m.K = state->K; m.C = state->B; m.HW = state->H * state->W; m.n_obs = n_obs;
+    m.sed[0] = state->sed[0]; m.sed[1] = state->sed[1]; m.morph[0] = state->morph[0]; m.morph[1] = state->morph[1];
+    m.cur = state->cur; m.active = state->active; m.it = state->it;
+    m.lipschitz = state->lipschitz; m.mse = state->mse; m.mse_capacity = state->mse_capacity;
+    m.fix_sed = state->fix_sed; m.fix_morph = state->fix_morph; m.approximate_L = approximate_L;
+    for (int o = 0; o < n_obs; ++o) {
+        if ((rc = check_batch(obs[o]))) return rc;
+        const scarlet_batch *ob = obs[o];
+        if (ob->S != state->S || ob->K != state->K || ob->H != state->H || ob->W != state->W || band0[o] < 0 ||
+            band0[o] + ob->B > state->B || ob->mse_capacity < 1)
+            return set_err(SCARLET_E_ARG, "an observation does not fit the model frame");
+        m.obs[o].sed[0] = ob->sed[0]; m.obs[o].sed[1] = ob->sed[1]; m.obs[o].morph[0] = ob->morph[0]; m.obs[o].morph[1] = ob->morph[1];
+        m.obs[o].cur = ob->cur; m.obs[o].it = ob->it; m.obs[o].active = ob->active;
+        m.obs[o].mse = ob->mse; m.obs[o].mse_capacity = ob->mse_capacity; m.obs[o].B = ob->B; m.obs[o].band0 = band0[o];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // scratch for the approximate Lipschitz sums: the state's convergence-sum area is free until the update runs
+    double *approx = ws_conv(state);
+    int *d_count = (int *)((char *)state->workspace + base_workspace_bytes(state) - 64);
+    const dim3 gridc((m.HW + 4 * SC_BLOCK - 1) / (4 * SC_BLOCK), m.S * m.K);
+    int launched = 0;
+    for (int i = 0; i < max_iter; ++i) {
+        hipLaunchKernelGGL(k_multi_scatter, gridc, dim3(SC_BLOCK), 0, st, m);
+        for (int o = 0; o < n_obs; ++o)
+            if ((rc = scarlet_backward_gradients(obs[o], 0, stream))) return rc;
+        // exact L of the FULL factors (blend.py:205-218): the state's own gradient pass (its loss and gradients
+        // are overwritten below); approximate L: the two sums of squares
+        if (approximate_L) hipLaunchKernelGGL(k_multi_approx, dim3(m.S), dim3(SC_BLOCK), 0, st, m, approx);
+        else if ((rc = scarlet_backward_gradients(state, 0, stream))) return rc;
+        hipLaunchKernelGGL(k_multi_loss, dim3((m.S + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0, st, m, (const double *)approx);
+        hipLaunchKernelGGL(k_multi_step, gridc, dim3(SC_BLOCK), 0, st, m);
+        if ((rc = launch_update(state, 1, 0, stream))) return rc;
+        if ((rc = scarlet_check_convergence(state, e_rel, stream))) return rc;
+        ++launched;
+        if (check_every > 0 && (i + 1) % check_every == 0 && i + 1 < max_iter) {
+            int h_count = 0;
+            hipLaunchKernelGGL(k_count_active, dim3(1), dim3(SC_BLOCK), 0, st, state->active, state->S, d_count);
+            HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (h_count == 0) break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return launched;
+}
+
 // ------------------------------------------------------------------------------------
 // ExtendedSource initialisation (source.py:139-180), float64 tile like the reference's
 // float64 coadd (bg_rms is float64 there), one workgroup per component.

@@ -404,13 +404,18 @@ def test_several_observations_match_the_reference(scarlet):
         else:
             obs = [scarlet.Observation(images, channels=ch).match(frame),
                    scarlet.Observation(g["twice_images2"], channels=ch).match(frame)]
-        blend = scarlet.Blend(srcs, obs)
-        blend.fit(8, e_rel=0)
-        assert blend.it == 8
-        assert rel_err(blend.mse, g[tag + "_mse"]) < 1e-5
-        assert rel_err(np.array([npy(c.morph) for c in blend.components]), g[tag + "_morph"]) < 1e-5
-        assert rel_err(np.array([npy(c.sed) for c in blend.components]), g[tag + "_sed"]) < 1e-5
-        assert_array_equal(np.array([c.pixel_center for c in blend.components]), g[tag + "_center"])
+        for python_pipeline in (False, True):          # device loop (scarlet_fit_multi) and host-side combination
+            if python_pipeline:
+                srcs = [scarlet.ExtendedSource(frame, p, full, bg) for p in cen]
+            blend = scarlet.Blend(srcs, obs)
+            blend.python_pipeline = python_pipeline
+            assert blend._builtin_pipeline() == (not python_pipeline)
+            blend.fit(8, e_rel=0)
+            assert blend.it == 8
+            assert rel_err(blend.mse, g[tag + "_mse"]) < 1e-5
+            assert rel_err(np.array([npy(c.morph) for c in blend.components]), g[tag + "_morph"]) < 1e-5
+            assert rel_err(np.array([npy(c.sed) for c in blend.components]), g[tag + "_sed"]) < 1e-5
+            assert_array_equal(np.array([c.pixel_center for c in blend.components]), g[tag + "_center"])
 
 
 def test_approximate_L_with_two_observations(scarlet):
