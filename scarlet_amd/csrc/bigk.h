@@ -39,6 +39,38 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_resid(GradArgs a, float *resi
     float *G = resid + (size_t)s * B * HW;
     double loss = 0;
     const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    if ((HW & 3) == 0) {
+        // 16 B per lane on every stream (K morphologies, B images [, B weights], B planes of G out)
+        const int HW4 = HW >> 2, g_end = p_end >> 2;
+        const float4 *mor4 = reinterpret_cast<const float4 *>(mor), *img4 = reinterpret_cast<const float4 *>(img);
+        const float4 *wgt4 = reinterpret_cast<const float4 *>(wgt);
+        float4 *G4 = reinterpret_cast<float4 *>(G);
+        for (int g = tile * (SC_TILE_PIX >> 2) + threadIdx.x; g < g_end; g += SC_BLOCK) {
+            float4 model[SC_BMAX];
+#pragma unroll
+            for (int b = 0; b < SC_BMAX; ++b) model[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < K; ++k) {
+                const float4 m = mor4[(size_t)k * HW4 + g];
+#pragma unroll
+                for (int b = 0; b < SC_BMAX; ++b)
+                    if (b < B) {
+                        const float sk = sed_s[k * SC_BMAX + b];
+                        model[b].x += sk * m.x; model[b].y += sk * m.y; model[b].z += sk * m.z; model[b].w += sk * m.w;
+                    }
+            }
+#pragma unroll
+            for (int b = 0; b < SC_BMAX; ++b)
+                if (b < B) {
+                    const float4 im = img4[(size_t)b * HW4 + g];
+                    const float4 w = wgt ? wgt4[(size_t)b * HW4 + g] : make_float4(a.weight_scalar, a.weight_scalar, a.weight_scalar, a.weight_scalar);
+                    const float d0 = w.x * (model[b].x - im.x), d1 = w.y * (model[b].y - im.y);
+                    const float d2 = w.z * (model[b].z - im.z), d3 = w.w * (model[b].w - im.w);
+                    loss += (double)d0 * (double)d0; loss += (double)d1 * (double)d1;
+                    loss += (double)d2 * (double)d2; loss += (double)d3 * (double)d3;
+                    G4[(size_t)b * HW4 + g] = make_float4(w.x * d0, w.y * d1, w.z * d2, w.w * d3);
+                }
+        }
+    } else
     for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
         float model[SC_BMAX];
 #pragma unroll
@@ -97,6 +129,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_gram(GradArgs a)
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = 0.f;
     const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    // (a 16 B per lane form of this loop was measured slower: 128 live accumulators and operands spill)
     for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
         float m1[SC_CHUNK], m2[SC_CHUNK];
 #pragma unroll
@@ -262,6 +295,37 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_step(GradArgs a, const float 
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = 0.f;
     const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    if ((HW & 3) == 0) {
+        const int HW4 = HW >> 2, g_end = p_end >> 2;
+        const float4 *mor4 = reinterpret_cast<const float4 *>(mor), *G4 = reinterpret_cast<const float4 *>(G);
+        float4 *mout4 = reinterpret_cast<float4 *>(mout);
+        for (int g = tile * (SC_TILE_PIX >> 2) + threadIdx.x; g < g_end; g += SC_BLOCK) {
+            float4 gb[SC_BMAX];
+#pragma unroll
+            for (int b = 0; b < SC_BMAX; ++b) gb[b] = b < B ? G4[(size_t)b * HW4 + g] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < SC_CHUNK; ++i) {
+                const int k = ch * SC_CHUNK + i;
+                if (k < K) {
+                    const float4 m = mor4[(size_t)k * HW4 + g];
+                    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int b = 0; b < SC_BMAX; ++b) {
+                        float r = acc[i * SC_BMAX + b];
+                        r += gb[b].x * m.x; r += gb[b].y * m.y; r += gb[b].z * m.z; r += gb[b].w * m.w;
+                        acc[i * SC_BMAX + b] = r;
+                        const float sk = sed_s[i * SC_BMAX + b];
+                        gm.x += sk * gb[b].x; gm.y += sk * gb[b].y; gm.z += sk * gb[b].z; gm.w += sk * gb[b].w;
+                    }
+                    float4 o;
+                    if (a.raw_gradient) o = gm;
+                    else if (fixm[i]) o = m;
+                    else o = make_float4(m.x - step_morph * gm.x, m.y - step_morph * gm.y, m.z - step_morph * gm.z, m.w - step_morph * gm.w);
+                    mout4[(size_t)k * HW4 + g] = o;
+                }
+            }
+        }
+    } else
     for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
         float gb[SC_BMAX];
 #pragma unroll
