@@ -160,7 +160,10 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_gram(GradArgs a)
 // then misses lambda_1 by at most n / (e 2^(SC_SQUARINGS + 1)) relative (< 1e-8), whatever the
 // spectral gaps.  Each lane owns a 4 x 4 block of the 32 x 32 product.
 #define SC_SQUARINGS 30
-__global__ __launch_bounds__(SC_WAVE) void k_bigk_lipschitz(GradArgs a)
+// One WORKGROUP per scene: the 30 dependent 32 x 32 x 32 float64 products are the whole cost of this pass (a
+// single wave took 0.24 ms for BASELINE config 5 whatever the number of scenes); four waves share each product,
+// a thread owns a 2 x 2 block, operands are read from LDS four k at a time.
+__global__ __launch_bounds__(SC_BLOCK) void k_bigk_lipschitz(GradArgs a)
 {
     const int s = blockIdx.x;
     if (!a.active[s]) return;
@@ -169,11 +172,13 @@ __global__ __launch_bounds__(SC_WAVE) void k_bigk_lipschitz(GradArgs a)
     __shared__ double Gm[SC_KBIG][LD], M0[SC_KBIG][LD], M1[SC_KBIG][LD];
     __shared__ double ata[SC_BMAX * SC_BMAX];
     __shared__ float sed_s[SC_KBIG * SC_BMAX];
-    const int lane = threadIdx.x;
+    __shared__ double red[SC_NWAVES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool w0 = tid < SC_WAVE;                      // the scalar parts run on the first wave, as before
     const int c0 = a.cur[s];
-    for (int i = lane; i < K * B; i += SC_WAVE)
+    for (int i = tid; i < K * B; i += SC_BLOCK)
         sed_s[(i / B) * SC_BMAX + (i % B)] = a.sed[c0][(size_t)s * K * B + i];
-    for (int i = lane; i < SC_KBIG * SC_KBIG; i += SC_WAVE) {
+    for (int i = tid; i < SC_KBIG * SC_KBIG; i += SC_BLOCK) {
         const int k = i / SC_KBIG, k2 = i - k * SC_KBIG;
         double r = 0;
         if (k < K && k2 < K) {
@@ -184,83 +189,79 @@ __global__ __launch_bounds__(SC_WAVE) void k_bigk_lipschitz(GradArgs a)
         Gm[k][k2] = r;
     }
     double loss = 0;
-    for (int t = 0; t < a.T; ++t) loss += a.partials[((size_t)s * a.T + t) * P];
+    if (w0) for (int t = 0; t < a.T; ++t) loss += a.partials[((size_t)s * a.T + t) * P];
     __syncthreads();
     double trace = 0;
-    if (lane < SC_KBIG) trace = Gm[lane][lane];
-    trace = wave_sum(trace);
+    if (tid < SC_KBIG) trace = Gm[tid][tid];
+    trace = block_sum(trace, red);
     const int it_new = a.it[s] + 1;
-    double L_sed, L_morph;
+    double L_sed = 0, L_morph = 0;
     if (a.approximate_L) {
         double LS = 0;
-        for (int i = lane; i < K * B; i += SC_WAVE) { const float v = sed_s[(i / B) * SC_BMAX + (i % B)]; LS += (double)v * v; }
-        LS = wave_sum(LS);
+        for (int i = tid; i < K * B; i += SC_BLOCK) { const float v = sed_s[(i / B) * SC_BMAX + (i % B)]; LS += (double)v * v; }
+        LS = block_sum(LS, red);
         double LA = trace;
         if (it_new > 1 && loss > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) { LA *= 2; LS *= 2; }
-        L_sed = LA; L_morph = LS;
+        L_sed = LA; L_morph = LS;          // (loss is valid on the first wave, which is the one that writes)
     } else {
         // ---- lambda_max(S S^T)
         const double inv = 1.0 / trace;
-        for (int i = lane; i < SC_KBIG * SC_KBIG; i += SC_WAVE) M0[i / SC_KBIG][i % SC_KBIG] = Gm[i / SC_KBIG][i % SC_KBIG] * inv;
+        for (int i = tid; i < SC_KBIG * SC_KBIG; i += SC_BLOCK) M0[i / SC_KBIG][i % SC_KBIG] = Gm[i / SC_KBIG][i % SC_KBIG] * inv;
         __syncthreads();
-        const int bi = (lane >> 3) << 2, bj = (lane & 7) << 2;
+        const int bi = (tid >> 4) << 1, bj = (tid & 15) << 1;
         double (*src)[LD] = M0, (*dst)[LD] = M1;
         for (int q = 0; q < SC_SQUARINGS; ++q) {
-            double acc[4][4];
+            double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+#pragma unroll 2
+            for (int k = 0; k < SC_KBIG; k += 4) {
+                double u0[4], u1[4], v0[4], v1[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int e = 0; e < 4; ++e) { u0[e] = src[bi][k + e]; u1[e] = src[bi + 1][k + e]; v0[e] = src[k + e][bj]; v1[e] = src[k + e][bj + 1]; }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] = 0;
-            for (int k = 0; k < SC_KBIG; ++k) {
-                double av[4], bv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { av[r] = src[bi + r][k]; bv[r] = src[k][bj + r]; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[r][c] += av[r] * bv[c];
+                for (int e = 0; e < 4; ++e) { a00 += u0[e] * v0[e]; a01 += u0[e] * v1[e]; a10 += u1[e] * v0[e]; a11 += u1[e] * v1[e]; }
             }
-            double tr = 0;
-            if (bi == bj) tr = (acc[0][0] + acc[1][1]) + (acc[2][2] + acc[3][3]);
-            tr = wave_sum(tr);
-            const double sc = 1.0 / tr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dst[bi + r][bj + c] = acc[r][c] * sc;
+            // renormalised by the trace every fourth squaring: lambda_1 >= 1/32 of the trace, so four squarings
+            // without it shrink the dominant entries to no less than 2^-80 (float64: no underflow)
+            double sc = 1.0;
+            if ((q & 3) == 3 || q == SC_SQUARINGS - 1) {
+                double tr = (bi == bj) ? a00 + a11 : 0.0;
+                tr = block_sum(tr, red);
+                sc = 1.0 / tr;
+            }
+            dst[bi][bj] = a00 * sc; dst[bi][bj + 1] = a01 * sc; dst[bi + 1][bj] = a10 * sc; dst[bi + 1][bj + 1] = a11 * sc;
             __syncthreads();
             double (*tmp)[LD] = src; src = dst; dst = tmp;
         }
-        // heaviest column of the (rank-one) power, Rayleigh quotient with G
-        double best = lane < SC_KBIG ? src[lane][lane] : -1.0;
-        int bidx = lane;
-        for (int o = 32; o > 0; o >>= 1) {
-            const double b2 = __shfl_xor(best, o, SC_WAVE);
-            const int i2 = __shfl_xor(bidx, o, SC_WAVE);
-            if (b2 > best || (b2 == best && i2 < bidx)) { best = b2; bidx = i2; }
+        if (w0) {
+            // heaviest column of the (rank-one) power, Rayleigh quotient with G
+            double best = lane < SC_KBIG ? src[lane][lane] : -1.0;
+            int bidx = lane;
+            for (int o = 32; o > 0; o >>= 1) {
+                const double b2 = __shfl_xor(best, o, SC_WAVE);
+                const int i2 = __shfl_xor(bidx, o, SC_WAVE);
+                if (b2 > best || (b2 == best && i2 < bidx)) { best = b2; bidx = i2; }
+            }
+            double v = lane < SC_KBIG ? src[lane][bidx] : 0.0, gv = 0;
+            if (lane < SC_KBIG) dst[0][lane] = v;
+            wave_sync();
+            if (lane < SC_KBIG)
+                for (int j = 0; j < SC_KBIG; ++j) gv += Gm[lane][j] * dst[0][j];
+            const double num = wave_sum(v * gv), den = wave_sum(v * v);
+            L_sed = num / den;
+            // ---- lambda_max(A^T A): the smaller of the two Gram matrices of the SED matrix (<= 8 x 8)
+            const int n = K < B ? K : B;
+            for (int i = lane; i < n * n; i += SC_WAVE) {
+                const int x = i / n, y = i - x * n;
+                double r = 0;
+                if (K < B) for (int b = 0; b < B; ++b) r += (double)sed_s[x * SC_BMAX + b] * sed_s[y * SC_BMAX + b];
+                else       for (int k = 0; k < K; ++k) r += (double)sed_s[k * SC_BMAX + x] * sed_s[k * SC_BMAX + y];
+                ata[x * n + y] = r;
+            }
+            wave_sync();
+            if (lane == 0) L_morph = jacobi_lambda_max(ata, n, n);
         }
-        double v = lane < SC_KBIG ? src[lane][bidx] : 0.0, gv = 0;
-        if (lane < SC_KBIG) dst[0][lane] = v;
-        __syncthreads();
-        if (lane < SC_KBIG)
-            for (int j = 0; j < SC_KBIG; ++j) gv += Gm[lane][j] * dst[0][j];
-        const double num = wave_sum(v * gv), den = wave_sum(v * v);
-        L_sed = num / den;
-        // ---- lambda_max(A^T A): the smaller of the two Gram matrices of the SED matrix (<= 8 x 8)
-        const int n = K < B ? K : B;
-        for (int i = lane; i < n * n; i += SC_WAVE) {
-            const int x = i / n, y = i - x * n;
-            double r = 0;
-            if (K < B) for (int b = 0; b < B; ++b) r += (double)sed_s[x * SC_BMAX + b] * sed_s[y * SC_BMAX + b];
-            else       for (int k = 0; k < K; ++k) r += (double)sed_s[k * SC_BMAX + x] * sed_s[k * SC_BMAX + y];
-            ata[x * n + y] = r;
-        }
-        __syncthreads();
-        L_morph = 0;
-        if (lane == 0) L_morph = jacobi_lambda_max(ata, n, n);
-        L_morph = __shfl(L_morph, 0, SC_WAVE);
     }
-    if (lane == 0) {
+    if (tid == 0) {
         if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
         a.lipschitz[2 * s] = L_sed;
         a.lipschitz[2 * s + 1] = L_morph;

@@ -1072,7 +1072,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         hipLaunchKernelGGL(k_bigk_loss_from_planes, dim3((b->S + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0, st, ga,
                            (const double *)a.loss_part);
         hipLaunchKernelGGL(k_bigk_gram, dim3(ga.T, nch * (nch + 1) / 2, ga.S), dim3(SC_BLOCK), 0, st, ga);
-        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(ga.S), dim3(SC_WAVE), 0, st, ga);
+        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga);
         prof_stop(st); prof_start(1, st);
         hipLaunchKernelGGL(k_bigk_step, dim3(ga.T, nch, ga.S), dim3(SC_BLOCK), 0, st, ga, (const float *)resid);
         hipLaunchKernelGGL(k_bigk_sed, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga);
@@ -1213,7 +1213,7 @@ static int backward_impl(scarlet_batch *b, int approximate_L, int raw_gradient, 
         prof_start(0, st);
         hipLaunchKernelGGL(k_bigk_resid, grid, dim3(SC_BLOCK), 0, st, a, resid);
         hipLaunchKernelGGL(k_bigk_gram, dim3(a.T, nch * (nch + 1) / 2, a.S), dim3(SC_BLOCK), 0, st, a);
-        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_WAVE), 0, st, a);
+        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
         prof_stop(st); prof_start(1, st);
         hipLaunchKernelGGL(k_bigk_step, dim3(a.T, nch, a.S), dim3(SC_BLOCK), 0, st, a, (const float *)resid);
         hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
