@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from scarlet_amd import synth
 from scarlet_amd.batch import BlendBatch
-S = 10000
+S = int(os.environ.get("STAMP_S", "10000"))
 d = synth.make_batch(0, 512)
 reps = (S + 511) // 512
 imgs = np.tile(d["images"], (reps, 1, 1, 1))[:S]; cen = np.tile(d["centers"], (reps, 1, 1))[:S]
