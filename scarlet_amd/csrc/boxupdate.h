@@ -21,12 +21,14 @@
 #pragma once
 #include "engine.h"
 
-#define SC_UB_R 31                                   // box half-size: complete for the sweep levels <= 62
-#define SC_UB_LW (2 * SC_UB_R + 3)
-#define SC_UB_FLOATS ((2 * SC_UB_R + 1) * SC_UB_LW)
-#define SC_UB_N 64                                   // padded box side: four 16-wide MFMA tiles
-#define SC_UB_NT (SC_UB_N / 16)
+// Two box sizes: R = 31 (63 x 63, complete for the sweep levels <= 62, swept by ONE wave without barriers) for
+// every component, and R = 63 (127 x 127, levels <= 126, compact levels on one wave and the rest level-synchronously
+// on the workgroup) for the components the first size flagged; only what the second one flags too goes to the
+// full-frame kernel.
 #define SC_UB_BR 16                                  // rows of X per band in LDS
+__host__ __device__ constexpr int ub_lw(int R) { return 2 * R + 3; }
+__host__ __device__ constexpr int ub_floats(int R) { return (2 * R + 1) * (2 * R + 3); }
+__host__ __device__ constexpr int ub_n(int R) { return 2 * R + 2; }       // padded box side: 64 / 128 = 4 / 8 MFMA tiles
 // T = X B[:, box] never leaves the registers: wave w owns the 16 box columns 16 w .. 16 w + 15 of T for ALL
 // window rows (one MFMA accumulator per band of 16 rows), and the accumulator layout -- lane (lr, lq), element
 // r holds T[16 band + 4 lq + r][16 w + lr] -- is exactly a B operand of the second product when its k steps
@@ -35,20 +37,24 @@
 // Measured alternatives (profiles/r02_notes.md): T in LDS (41 KB: two or three workgroups per CU instead of
 // four) 1.1 - 1.6 x slower; bands of 32 rows with two accumulation chains per wave spill at 128 VGPRs, slower.
 
-__host__ __device__ inline size_t ub_lds_floats(int H, int W)
+__host__ __device__ inline size_t ub_lds_floats(int H, int W, int R)
 {
     const int hp = round16(H), wp = round16(W);
     const size_t stage = (size_t)SC_UB_BR * tile_stride(wp);          // the band of X and the box share their space
-    return (stage > SC_UB_FLOATS ? stage : (size_t)SC_UB_FLOATS) + 2 * hp + 4 * wp + wp + SC_UB_N;
+    return (stage > (size_t)ub_floats(R) ? stage : (size_t)ub_floats(R)) + 2 * hp + 4 * wp + wp + ub_n(R);
 }
 
-// NB: bands of 16 window rows the kernel is built for (8: frames up to 128 rows, 16: up to 256)
-template <int NB>
-__global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a, int *fallback, long long *stamps_all)
+// NB: bands of 16 window rows the kernel is built for (8: frames up to 128 rows, 16: up to 256); R: box half-size.
+// `only` != NULL: run for the components flagged there (the second box size after the first)
+template <int NB, int R>
+__global__ __launch_bounds__(SC_BLOCK, R <= 31 ? 4 : 2) void k_source_update_box(UpdateArgs a, const int *only, int *fallback, long long *stamps_all)
 {
+    constexpr int SC_UB_R = R, SC_UB_LW = ub_lw(R), SC_UB_FLOATS = ub_floats(R), SC_UB_N = ub_n(R), SC_UB_NT = SC_UB_N / 16;
+    constexpr int CTW = SC_UB_NT / SC_NWAVES;             // column tiles of T per wave (1 or 2)
     extern __shared__ __align__(16) float lds[];
     const int c = blockIdx.x, s = c / a.K;
     if (!a.force_it0 && !a.active[s]) return;
+    if (only && !only[c]) return;
     long long *stamps = stamps_all ? stamps_all + (size_t)c * 16 : nullptr;
 #define UB_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     UB_STAMP(0);
@@ -64,6 +70,7 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a,
     __shared__ double shf[2];
     __shared__ int stat;
     __shared__ int hyb[2];
+    __shared__ int lastpos;
     const int c0 = a.cur[s];
     const int wbuf = a.in_iteration ? 1 - c0 : c0;
     float *gm = a.morph[wbuf] + (size_t)c * HW;
@@ -106,13 +113,17 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a,
     const int nbh = min(sw.h, by0 + bh - sw.y0) - ia, nbw = min(sw.w, bx0 + bw - sw.x0) - ja;
     // global loads are requested as early as their addresses are known and consumed late: the box (X inside it,
     // 16 values per thread) and the first band of window rows now, under the float64 trigonometry of the vectors
-    constexpr int NBX = (SC_UB_FLOATS / SC_UB_LW * (2 * SC_UB_R + 1) + SC_BLOCK - 1) / SC_BLOCK;      // 63 * 63 / 256 -> 16
+    // (the large box is read when it is stored instead: 64 registers per thread are not free)
+    constexpr bool BOX_REGS = R <= 31;
+    constexpr int NBX = BOX_REGS ? ((2 * R + 1) * (2 * R + 1) + SC_BLOCK - 1) / SC_BLOCK : 1;      // 63 * 63 / 256 -> 16
     float bxr[NBX];
+    if (BOX_REGS) {
 #pragma unroll
-    for (int j = 0; j < NBX; ++j) {
-        const int i = threadIdx.x + j * SC_BLOCK;
-        const int y = i / bw, x = i - y * bw;
-        bxr[j] = i < bh * bw ? gm[(by0 + y) * W + bx0 + x] : 0.f;
+        for (int j = 0; j < NBX; ++j) {
+            const int i = threadIdx.x + j * SC_BLOCK;
+            const int y = i / bw, x = i - y * bw;
+            bxr[j] = i < bh * bw ? gm[(by0 + y) * W + bx0 + x] : 0.f;
+        }
     }
     Tile bt; bt.H = bh; bt.W = bw; bt.LW = SC_UB_LW; bt.m = box;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
@@ -130,11 +141,18 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a,
     };
     if (mode == 1) load_band(0);
     auto store_box = [&]() {
+        if (BOX_REGS) {
 #pragma unroll
-        for (int j = 0; j < NBX; ++j) {
-            const int i = threadIdx.x + j * SC_BLOCK;
-            const int y = i / bw, x = i - y * bw;
-            if (i < bh * bw) box[y * SC_UB_LW + x] = bxr[j];
+            for (int j = 0; j < NBX; ++j) {
+                const int i = threadIdx.x + j * SC_BLOCK;
+                const int y = i / bw, x = i - y * bw;
+                if (i < bh * bw) box[y * SC_UB_LW + x] = bxr[j];
+            }
+        } else {
+            for (int i = threadIdx.x; i < bh * bw; i += SC_BLOCK) {
+                const int y = i / bw, x = i - y * bw;
+                box[y * SC_UB_LW + x] = gm[(by0 + y) * W + bx0 + x];
+            }
         }
     };
     if (mode == 1) {
@@ -150,11 +168,12 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a,
         UB_STAMP(2);
         // GEMM 1: T[:, box columns] = X (h x w, zero outside the window) . Hankel(bv); X streams through `stage`,
         // wave `wid` accumulates the box columns 16 wid .. 16 wid + 15 for every band (registers)
-        f32x4 Tacc[NB];
+        f32x4 Tacc[NB][CTW];
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
             const int i0 = bi * SC_UB_BR;
-            Tacc[bi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < CTW; ++q) Tacc[bi][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (i0 < hp) {
                 __syncthreads();                                   // vectors ready / previous band consumed
 #pragma unroll
@@ -172,21 +191,27 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a,
                         vloc += ((i0 + r - ry) & 1) ? -x : x;
                     }
                 }
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc[CTW];
+#pragma unroll
+                for (int q = 0; q < CTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const float *arow = stage + lr * SW;
 #pragma unroll 4
                 for (int k0 = 0; k0 < wp; k0 += 4) {
                     const int k = k0 + lq;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k], bv[min(k + ja + wid * 16 + lr, 2 * wp - 1)], acc, 0, 0, 0);
+                    const float xa = arow[k];
+#pragma unroll
+                    for (int q = 0; q < CTW; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, bv[min(k + ja + (wid + SC_NWAVES * q) * 16 + lr, 2 * wp - 1)], acc[q], 0, 0, 0);
                 }
-                Tacc[bi] = acc;
+#pragma unroll
+                for (int q = 0; q < CTW; ++q) Tacc[bi][q] = acc[q];
             }
         }
         if (need_rank1 && threadIdx.x < wp) zv[threadIdx.x] = threadIdx.x < w ? vloc : 0.f;
         __syncthreads();                                           // T and v complete; the last band is consumed
         store_box();                                               // (the box takes the band's place; read from GEMM 2's epilogue on)
         UB_STAMP(3);
-        if (need_rank1 && threadIdx.x < SC_UB_N) {                 // z[j] = sum_j2 C[j][j2] v[j2] for the box columns
+        if (need_rank1 && (int)threadIdx.x < SC_UB_N) {            // z[j] = sum_j2 C[j][j2] v[j2] for the box columns
             const int j = ja + threadIdx.x;
             float zloc = 0.f;
             if (j < w)
@@ -197,40 +222,51 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a,
         UB_STAMP(4);
         // GEMM 2: Y[box rows, box columns] = Hankel(av)[box rows, :] . T ; epilogue combines with X in the box.
         // Wave `wid`: its column tile of T from the accumulators, the four row tiles of the box.
-        f32x4 Y[SC_UB_NT];
+        // (row tiles in groups of four: the accumulators of a group, 4 x CTW, stay in registers)
 #pragma unroll
-        for (int rt2 = 0; rt2 < SC_UB_NT; ++rt2) Y[rt2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int ct2 = wid;
-        if (ct2 * 16 < nbw) {
+        for (int rg = 0; rg < SC_UB_NT; rg += 4) {
+            f32x4 Y[4][CTW];
 #pragma unroll
-            for (int bi = 0; bi < NB; ++bi)
-                if (bi * 16 < hp) {
+            for (int rt2 = 0; rt2 < 4; ++rt2)
+#pragma unroll
+                for (int q = 0; q < CTW; ++q) Y[rt2][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (rg * 16 < nbh) {
+#pragma unroll
+                for (int bi = 0; bi < NB; ++bi)
+                    if (bi * 16 < hp) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int k = bi * 16 + 4 * lq + r;
+#pragma unroll
+                            for (int rt2 = 0; rt2 < 4; ++rt2) {
+                                const float aa = av[min(ia + (rg + rt2) * 16 + lr + k, 2 * hp - 1)];
+#pragma unroll
+                                for (int q = 0; q < CTW; ++q)
+                                    Y[rt2][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, Tacc[bi][q][r], Y[rt2][q], 0, 0, 0);
+                            }
+                        }
+                    }
+            }
+#pragma unroll
+            for (int rt2 = 0; rt2 < 4; ++rt2)
+#pragma unroll
+                for (int q = 0; q < CTW; ++q) {
+                    const int ct2 = wid + SC_NWAVES * q, rt = rg + rt2;
+                    if (rt * 16 >= nbh || ct2 * 16 >= nbw) continue;
+                    const f32x4 acc = Y[rt2][q];
+                    const int jl = ct2 * 16 + lr, j = ja + jl;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int k = bi * 16 + 4 * lq + r;
-                        const float tb = Tacc[bi][r];
-#pragma unroll
-                        for (int rt2 = 0; rt2 < SC_UB_NT; ++rt2)
-                            Y[rt2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[min(ia + rt2 * 16 + lr + k, 2 * hp - 1)], tb, Y[rt2], 0, 0, 0);
+                        const int il = rt * 16 + lq * 4 + r, i = ia + il;
+                        if (il < nbh && jl < nbw) {
+                            float *p = &box[(sw.y0 + i - by0) * SC_UB_LW + (sw.x0 + j - bx0)];
+                            const float x = *p;
+                            float y2 = acc[r];
+                            if (need_rank1) y2 += (((i - ry) & 1) ? -sy : sy) * vsum[jl];
+                            *p = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
+                        }
                     }
                 }
-        }
-#pragma unroll
-        for (int rt2 = 0; rt2 < SC_UB_NT; ++rt2) {
-            if (rt2 * 16 >= nbh || ct2 * 16 >= nbw) continue;
-            const f32x4 acc = Y[rt2];
-            const int jl = ct2 * 16 + lr, j = ja + jl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int il = rt2 * 16 + lq * 4 + r, i = ia + il;
-                if (il < nbh && jl < nbw) {
-                    float *p = &box[(sw.y0 + i - by0) * SC_UB_LW + (sw.x0 + j - bx0)];
-                    const float x = *p;
-                    float y2 = acc[r];
-                    if (need_rank1) y2 += (((i - ry) & 1) ? -sy : sy) * vsum[jl];
-                    *p = (x <= 0.f) ? 0.f : 0.5f * x + 0.5f * y2;
-                }
-            }
         }
         __syncthreads();
     } else if (mode == 2) {
@@ -269,14 +305,20 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a,
             lastv[j] = (gl && g < (HW >> 2)) ? reinterpret_cast<const float4 *>(gl)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    // radial monotonicity on the box: levels 1 .. 62, one wave, no barriers
+    // radial monotonicity on the box.  R = 31: levels 1 .. 62 on one wave, no barriers.  R = 63: the compact levels
+    // (1 .. 46) on one wave, the rest level-synchronously on the workgroup; valid while it ends by level 2 R
     if (threadIdx.x < SC_WAVE) {
         int done, quiet;
-        wave_monotonic<float>(bt, cy - by0, cx - bx0, 0.f, &done, &quiet, 0.f, 2 * SC_UB_R);
+        if (R <= 31) wave_monotonic<float>(bt, cy - by0, cx - bx0, 0.f, &done, &quiet, 0.f, 2 * SC_UB_R);
+        else wave_monotonic<float>(bt, cy - by0, cx - bx0, 0.f, &done, &quiet);
         if (threadIdx.x == 0) { hyb[0] = done; hyb[1] = quiet; }
     }
     __syncthreads();
-    const int lstop = hyb[0];
+    int lstop = hyb[0];
+    if (R > 31 && lstop == (1 << 30)) {
+        lstop = monotonic_tile<false, float>(bt, cy - by0, cx - bx0, 0.f, &lastpos, 0.f, SC_COMPACT_LAST + 1, SC_COMPACT_LAST - hyb[1]);
+        if (lstop > 2 * SC_UB_R) lstop = 1 << 30;          // the box is complete only up to level 2 R
+    }
     UB_STAMP(6);
     if (stamps && threadIdx.x == 0) stamps[8] = lstop;
     if (lstop == (1 << 30)) {                              // the footprint leaves the box: full path, nothing written yet

@@ -48,9 +48,9 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
-                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER", "NO_BOX"};
+                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER", "NO_BOX", "NO_BOX2"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -1272,19 +1272,26 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
     }
     u.hybrid_sweep = opt(OPT_NO_HYBRID_SWEEP) ? 0 : 1;
     if ((b->H > 64 || b->W > 64) && b->H <= 256 && b->W <= 256 && b->monotonic && !opt(OPT_NO_BOX) &&
-        sizeof(float) * ub_lds_floats(b->H, b->W) <= LDS_LIMIT) {
-        // frames beyond the wave-level tile: the pipeline on the box around each peak (boxupdate.h); the kernels
-        // below then run only for the components whose footprint left the box
-        const size_t ldsb = sizeof(float) * ub_lds_floats(b->H, b->W);
+        sizeof(float) * ub_lds_floats(b->H, b->W, 63) <= LDS_LIMIT) {
+        // frames beyond the wave-level tile: the pipeline on the box around each peak (boxupdate.h) -- 63 x 63 for
+        // every component, 127 x 127 for those whose footprint left it; the kernels below then run only for the
+        // components that left the second box too
+        const size_t lds1 = sizeof(float) * ub_lds_floats(b->H, b->W, 31), lds2 = sizeof(float) * ub_lds_floats(b->H, b->W, 63);
         long long *dbg = debug_stamps((size_t)b->S * b->K * 16);
+        int *fb = ws_box_fallback(b);
+        hipStream_t st = (hipStream_t)stream;
         if (b->H <= 128) {
-            if ((rc = allow_lds(k_source_update_box<8>, ldsb))) return rc;
-            hipLaunchKernelGGL(k_source_update_box<8>, dim3(b->S * b->K), dim3(SC_BLOCK), ldsb, (hipStream_t)stream, u, ws_box_fallback(b), dbg);
+            if ((rc = allow_lds(k_source_update_box<8, 31>, lds1)) || (rc = allow_lds(k_source_update_box<8, 63>, lds2))) return rc;
+            hipLaunchKernelGGL((k_source_update_box<8, 31>), dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, (const int *)nullptr, fb, dbg);
+            if (!opt(OPT_NO_BOX2))
+                hipLaunchKernelGGL((k_source_update_box<8, 63>), dim3(b->S * b->K), dim3(SC_BLOCK), lds2, st, u, (const int *)fb, fb, (long long *)nullptr);
         } else {
-            if ((rc = allow_lds(k_source_update_box<16>, ldsb))) return rc;
-            hipLaunchKernelGGL(k_source_update_box<16>, dim3(b->S * b->K), dim3(SC_BLOCK), ldsb, (hipStream_t)stream, u, ws_box_fallback(b), dbg);
+            if ((rc = allow_lds(k_source_update_box<16, 31>, lds1)) || (rc = allow_lds(k_source_update_box<16, 63>, lds2))) return rc;
+            hipLaunchKernelGGL((k_source_update_box<16, 31>), dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, (const int *)nullptr, fb, dbg);
+            if (!opt(OPT_NO_BOX2))
+                hipLaunchKernelGGL((k_source_update_box<16, 63>), dim3(b->S * b->K), dim3(SC_BLOCK), lds2, st, u, (const int *)fb, fb, (long long *)nullptr);
         }
-        u.only_flagged = ws_box_fallback(b);
+        u.only_flagged = fb;
     }
     if (b->H <= 64 && b->W <= 64 && !opt(OPT_FORCE_BLOCK_UPDATE)) {
         // one wave per component, four components per workgroup (wave_ops.h)
