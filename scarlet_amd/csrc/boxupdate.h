@@ -13,8 +13,8 @@
 //     T = X B[:, box]   (h x w x 64)        Y = A[box, :] T   (64 x h x 64),
 // ~2.7 x fewer MFMAs than the full h x w x (h + w) products on a 128 x 128 window and ~6 x on 256 x 256, and
 // neither the frame-sized tile nor the frame-sized scratch has to live in LDS / HBM: X streams through LDS
-// once in bands of rows.  Each output element is accumulated over k in the same order as in
-// kspace_symmetry_tile, so inside the box the values are bit-identical to the full operator's.
+// once in bands of rows.  (The k sums run in a different order than in kspace_symmetry_tile: equal to float32
+// rounding, not bit for bit.)
 //
 // A component whose sweep does NOT end within the box (or the rare centred soft-symmetry window) is left
 // untouched and flagged in `fallback`; k_source_update<MODE> then runs for the flagged components only.
@@ -33,7 +33,7 @@ __host__ __device__ constexpr int ub_n(int R) { return 2 * R + 2; }       // pad
 // window rows (one MFMA accumulator per band of 16 rows), and the accumulator layout -- lane (lr, lq), element
 // r holds T[16 band + 4 lq + r][16 w + lr] -- is exactly a B operand of the second product when its k steps
 // enumerate (band, r): k(lq) = 16 band + 4 lq + r.  The Hankel operand A[i][k] = av[i + k] is read at that k.
-// (A permuted summation order over k; the values of T are bit-identical to kspace_symmetry_tile's.)
+// (A permuted summation order over k in both products: T is accumulated in two interleaved chains.)
 // Measured alternatives (profiles/r02_notes.md): T in LDS (41 KB: two or three workgroups per CU instead of
 // four) 1.1 - 1.6 x slower; bands of 32 rows with two accumulation chains per wave spill at 128 VGPRs, slower.
 
@@ -191,20 +191,25 @@ __global__ __launch_bounds__(SC_BLOCK, R <= 31 ? 4 : 2) void k_source_update_box
                         vloc += ((i0 + r - ry) & 1) ? -x : x;
                     }
                 }
-                f32x4 acc[CTW];
+                // two accumulation chains per tile (k steps 0, 2, 4 .. and 1, 3, 5 ..), added at the end: a dependent
+                // MFMA waits ~40 cycles for its accumulator, two interleaved chains hide half of it
+                f32x4 acc[CTW], acc2[CTW];
 #pragma unroll
-                for (int q = 0; q < CTW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < CTW; ++q) { acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[q] = acc[q]; }
                 const float *arow = stage + lr * SW;
-#pragma unroll 4
-                for (int k0 = 0; k0 < wp; k0 += 4) {
+#pragma unroll 2
+                for (int k0 = 0; k0 < wp; k0 += 8) {
                     const int k = k0 + lq;
-                    const float xa = arow[k];
+                    const float xa = arow[k], xb = arow[k + 4];
 #pragma unroll
-                    for (int q = 0; q < CTW; ++q)
-                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, bv[min(k + ja + (wid + SC_NWAVES * q) * 16 + lr, 2 * wp - 1)], acc[q], 0, 0, 0);
+                    for (int q = 0; q < CTW; ++q) {
+                        const int jc = ja + (wid + SC_NWAVES * q) * 16 + lr;
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, bv[min(k + jc, 2 * wp - 1)], acc[q], 0, 0, 0);
+                        acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, bv[min(k + 4 + jc, 2 * wp - 1)], acc2[q], 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int q = 0; q < CTW; ++q) Tacc[bi][q] = acc[q];
+                for (int q = 0; q < CTW; ++q) Tacc[bi][q] = acc[q] + acc2[q];
             }
         }
         if (need_rank1 && threadIdx.x < wp) zv[threadIdx.x] = threadIdx.x < w ? vloc : 0.f;
