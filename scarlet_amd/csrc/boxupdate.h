@@ -129,17 +129,25 @@ __global__ __launch_bounds__(SC_BLOCK, R <= 31 ? 4 : 2) void k_source_update_box
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
     const int hW = sw.h, wW = sw.w, wpW = round16(wW);
     // band of BR window rows x wp columns: element e = threadIdx.x + j * 256 -> (row e / wp, column e % wp)
-    constexpr int NBAND = SC_UB_BR * 256 / SC_BLOCK;             // values per thread for the widest frame (wp = 256)
-    float xr[NBAND];
-    auto load_band = [&](int i0) {
+    // values per thread and band: the NB = 8 instance serves frames up to 128 x 128 (wp <= 128: 8 values) and keeps
+    // TWO bands in flight -- with one, each band of the first product waited a full HBM round trip (~6 k cycles x 8
+    // bands, measured) --, the NB = 16 instance (wp <= 256: 16 values) one
+    constexpr int NBAND = NB == 8 ? 8 : 16, NPF = NB == 8 ? 2 : 1;
+    float xr[NPF][NBAND];
+    auto load_band = [&](int i0, int slot) {
 #pragma unroll
         for (int j = 0; j < NBAND; ++j) {
             const int e = threadIdx.x + j * SC_BLOCK;
             const int r = e / wpW, cc = e - r * wpW;
-            xr[j] = (e < SC_UB_BR * wpW && i0 + r < hW && cc < wW) ? gm[(sw.y0 + i0 + r) * W + sw.x0 + cc] : 0.f;
+            const float v = (e < SC_UB_BR * wpW && i0 + r < hW && cc < wW) ? gm[(sw.y0 + i0 + r) * W + sw.x0 + cc] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) if (q == slot) xr[q][j] = v;
         }
     };
-    if (mode == 1) load_band(0);
+    if (mode == 1) {
+        load_band(0, 0);
+        if (NPF > 1) load_band(SC_UB_BR, 1);
+    }
     auto store_box = [&]() {
         if (BOX_REGS) {
 #pragma unroll
@@ -180,10 +188,10 @@ __global__ __launch_bounds__(SC_BLOCK, R <= 31 ? 4 : 2) void k_source_update_box
                 for (int j = 0; j < NBAND; ++j) {
                     const int e = threadIdx.x + j * SC_BLOCK;
                     const int r = e / wp, cc = e - r * wp;
-                    if (e < BR * wp) stage[r * SW + cc] = xr[j];
+                    if (e < BR * wp) stage[r * SW + cc] = xr[bi % NPF][j];
                 }
                 __syncthreads();
-                if (i0 + BR < hp) load_band(i0 + BR);              // the next band: in flight under this band's MFMAs
+                if (i0 + NPF * BR < hp) load_band(i0 + NPF * BR, bi % NPF);     // NPF bands ahead: in flight under the MFMAs
                 if (need_rank1 && threadIdx.x < w) {               // v[j] = sum_i (-1)^(i - ry) X[i][j], i ascending
                     const int rows = min(BR, h - i0);
                     for (int r = 0; r < rows; ++r) {
@@ -362,11 +370,28 @@ __global__ __launch_bounds__(SC_BLOCK, R <= 31 ? 4 : 2) void k_source_update_box
     };
     if (vec4) {
         const int gpr = W >> 2, ngroups = HW >> 2;
+        const bool plain = regular && l0 < 0.f && l1 < 0.f;       // no thresholds, finite positive norm: the common case
         auto do_group = [&](int g, const float4 &l) {
             const int y = g / gpr, x = (g - y * gpr) << 2;
             float o[4];
-            if (regular && (y < by0 || y >= by0 + bh || x + 3 < bx0 || x >= bx0 + bw)) { o[0] = o[1] = o[2] = o[3] = 0.f; }
-            else {
+            // level(x, y) = 2 max(ax, ay) + min(ax, ay) <= lstop  <=>  ax <= axmax(ay): one bound per group's row
+            // instead of a level per pixel (as the fused kernel's final pass does); lstop <= 2 R keeps it inside the box
+            const int ay = y < cy ? cy - y : y - cy;
+            const int h1 = (lstop - ay) >> 1;
+            const int axmax = h1 >= ay ? h1 : lstop - 2 * ay;
+            const int xb0 = x - cx + axmax;                        // pixel e is inside the cut iff 0 <= xb0 + e <= 2 axmax
+            if (regular && (axmax < 0 || xb0 + 3 < 0 || xb0 > 2 * axmax)) { o[0] = o[1] = o[2] = o[3] = 0.f; }
+            else if (plain) {
+                const float *bp = box + (y - by0) * SC_UB_LW + (x - bx0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = (unsigned)(xb0 + e) <= (unsigned)(2 * axmax);
+                    float v = in ? bp[e] : 0.f;                    // (inside the cut implies inside the box)
+                    v = v < 0.f ? 0.f : v;
+                    const float q = v * rnorm;
+                    o[e] = fmaf(fmaf(-q, norm, v), rnorm, q);
+                }
+            } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = out_pixel(y, x + e);
             }

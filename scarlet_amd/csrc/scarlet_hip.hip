@@ -1280,7 +1280,7 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
         long long *dbg = debug_stamps((size_t)b->S * b->K * 16);
         int *fb = ws_box_fallback(b);
         hipStream_t st = (hipStream_t)stream;
-        if (b->H <= 128) {
+        if (b->H <= 128 && b->W <= 128) {
             if ((rc = allow_lds(k_source_update_box<8, 31>, lds1)) || (rc = allow_lds(k_source_update_box<8, 63>, lds2))) return rc;
             hipLaunchKernelGGL((k_source_update_box<8, 31>), dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, (const int *)nullptr, fb, dbg);
             if (!opt(OPT_NO_BOX2))
