@@ -45,16 +45,17 @@ __host__ __device__ inline size_t ub_lds_floats(int H, int W, int R)
 }
 
 // NB: bands of 16 window rows the kernel is built for (8: frames up to 128 rows, 16: up to 256); R: box half-size.
-// `only` != NULL: run for the components flagged there (the second box size after the first)
+// ub_component: the pipeline for component `c` by the calling workgroup (every return is uniform over it).
+// `list` / `count` != NULL (the small box): a component whose sweep leaves the box is appended to the list for the
+// large-box kernel; without them it is only flagged in `fallback` (the full-frame kernel runs for those).
 template <int NB, int R>
-__global__ __launch_bounds__(SC_BLOCK, R <= 31 ? 4 : 2) void k_source_update_box(UpdateArgs a, const int *only, int *fallback, long long *stamps_all)
+__device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, int *fallback, int *list, int *count, long long *stamps_all)
 {
     constexpr int SC_UB_R = R, SC_UB_LW = ub_lw(R), SC_UB_FLOATS = ub_floats(R), SC_UB_N = ub_n(R), SC_UB_NT = SC_UB_N / 16;
     constexpr int CTW = SC_UB_NT / SC_NWAVES;             // column tiles of T per wave (1 or 2)
     extern __shared__ __align__(16) float lds[];
-    const int c = blockIdx.x, s = c / a.K;
+    const int s = c / a.K;
     if (!a.force_it0 && !a.active[s]) return;
-    if (only && !only[c]) return;
     long long *stamps = stamps_all ? stamps_all + (size_t)c * 16 : nullptr;
 #define UB_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     UB_STAMP(0);
@@ -333,9 +334,12 @@ __global__ __launch_bounds__(SC_BLOCK, R <= 31 ? 4 : 2) void k_source_update_box
         if (lstop > 2 * SC_UB_R) lstop = 1 << 30;          // the box is complete only up to level 2 R
     }
     UB_STAMP(6);
-    if (stamps && threadIdx.x == 0) stamps[8] = lstop;
+    if (stamps && threadIdx.x == 0) { stamps[8] = lstop; stamps[9] = R; }
     if (lstop == (1 << 30)) {                              // the footprint leaves the box: full path, nothing written yet
-        if (threadIdx.x == 0) fallback[c] = 1;
+        if (threadIdx.x == 0) {
+            fallback[c] = 1;
+            if (list) list[atomicAdd(count, 1)] = c;       // (any order: the components are independent)
+        }
         return;
     }
     if (threadIdx.x == 0) {
@@ -454,4 +458,25 @@ __global__ __launch_bounds__(SC_BLOCK, R <= 31 ? 4 : 2) void k_source_update_box
     }
     UB_STAMP(7);
 #undef UB_STAMP
+}
+
+// NB: bands of 16 window rows the kernel is built for (8: frames up to 128 rows, 16: up to 256).
+// The small box: one workgroup per component, four per CU.
+template <int NB>
+__global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a, int *fallback, int *list, int *count, long long *stamps_all)
+{
+    ub_component<NB, 31>(a, blockIdx.x, fallback, list, count, stamps_all);
+}
+
+// The large box for the listed components: workgroup i takes list[i]; workgroups past the end of the list exit at
+// once -- after every listed one has been dispatched (~35 us for the 32768 components of config 3).  (The first form, one workgroup per
+// component of the batch with an early exit for the unlisted ones BETWEEN the listed ones, kept ~0.6 of the two
+// resident workgroups per CU busy: 0.7 ms for the ~4 % listed components of BASELINE config 3.  A loop over the
+// list inside the workgroup costs the register budget: the body's per-thread invariants get hoisted and spill.)
+template <int NB>
+__global__ __launch_bounds__(SC_BLOCK, 2) void k_source_update_box_listed(UpdateArgs a, int *fallback, const int *list, const int *count,
+                                                                           long long *stamps_all)
+{
+    if ((int)blockIdx.x >= *count) return;
+    ub_component<NB, 63>(a, list[blockIdx.x], fallback, nullptr, nullptr, stamps_all);
 }

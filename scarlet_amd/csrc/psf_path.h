@@ -536,6 +536,216 @@ __global__ __launch_bounds__(SC_BLOCK) void k_psf_model4(PsfArgs a)
         if (b < B) out[(size_t)b * HW4] = v[b];
 }
 
+// ---- three-pass form of an iteration on compact planes (K <= SC_KMAX): the morphology step needs only
+// lambda_max(A^T A) of the SEDs (blend.py:205-218), so the separate reduction pass over G and the morphologies
+// (k_grad_psf4) is not needed before it:
+//   k_psf_model4g : model planes + the Gram partials S S^T (the pass reads every morphology anyway)
+//   k_psf_conv    : model -> G
+//   k_step_psf4f  : morphology step + the SED-gradient partials sum_p G_b m_k of the same pass
+//   k_sed_step    : per scene: partial sums, both Lipschitz constants, SED step, loss record
+// Every sum keeps the per-thread order and the reduction tree of k_grad_psf4 / k_step_psf4: the results are
+// bit-identical to the four-pass form (SCARLET_NO_PSF3PASS=1 runs that one).
+template <int KM>
+__global__ __launch_bounds__(SC_BLOCK) void k_psf_model4g(PsfArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int c0 = a.cur[s], HW4 = (a.g.H * a.g.W) >> 2, K = a.K, B = a.B;
+    __shared__ float sed_s[KM * SC_BMAX];
+    __shared__ double red[SC_NWAVES][KM * (KM + 1) / 2];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
+        sed_s[(i / B) * SC_BMAX + (i % B)] = a.sed[c0][(size_t)s * K * B + i];
+    __syncthreads();
+    float sk[KM][SC_BMAX];               // scalars (SGPRs), as in k_step_psf4f
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < SC_BMAX; ++b)
+            sk[k][b] = (k < K && b < B) ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sed_s[k * SC_BMAX + b]))) : 0.f;
+    float gram[KM * (KM + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < KM * (KM + 1) / 2; ++i) gram[i] = 0.f;
+    const float4 *mor = reinterpret_cast<const float4 *>(a.morph[c0] + (size_t)s * K * HW4 * 4);
+    float4 *out = reinterpret_cast<float4 *>(a.real + (size_t)s * B * HW4 * 4);
+    const int g_end = min(HW4, (tile + 1) * (SC_TILE_PIX >> 2));
+    // (not unrolled: ~100 VGPRs keep four waves per SIMD in flight, which is what a streaming pass needs)
+#pragma unroll 1
+    for (int g = tile * (SC_TILE_PIX >> 2) + threadIdx.x; g < g_end; g += SC_BLOCK) {
+        float4 m[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) m[k] = k < K ? mor[(size_t)k * HW4 + g] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int b = 0; b < SC_BMAX; ++b)
+            if (b < B) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+                        v.x += sk[k][b] * m[k].x; v.y += sk[k][b] * m[k].y; v.z += sk[k][b] * m[k].z; v.w += sk[k][b] * m[k].w;
+                    }
+                out[(size_t)b * HW4 + g] = v;
+            }
+        int gi = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < KM; ++k2) {
+                gram[gi] += m[k].x * m[k2].x; gram[gi] += m[k].y * m[k2].y;
+                gram[gi] += m[k].z * m[k2].z; gram[gi] += m[k].w * m[k2].w;
+                ++gi;
+            }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    {
+        int gi = 0, go = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < KM; ++k2) {
+                if (k < K && k2 < K) {
+                    const double v = wave_sum((double)gram[gi]);
+                    if (lane == 0) red[wid][go] = v;
+                    ++go;
+                }
+                ++gi;
+            }
+    }
+    __syncthreads();
+    const int P = n_partials(K, B), NG = K * (K + 1) / 2;
+    double *po = a.partials + ((size_t)s * a.T + tile) * P + 1 + K * B;
+    for (int i = threadIdx.x; i < NG; i += SC_BLOCK) {
+        double r = 0;
+#pragma unroll
+        for (int w = 0; w < SC_NWAVES; ++w) r += red[w][i];
+        po[i] = r;
+    }
+}
+
+template <int KM, int BM>
+__global__ __launch_bounds__(SC_BLOCK, (KM * BM <= 32 ? 4 : 2)) void k_step_psf4f(PsfArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.g.H * a.g.W;
+    __shared__ double red[SC_NWAVES][KM * BM];
+    __shared__ double ATA[BM * BM];
+    __shared__ float sed_s[KM * BM];
+    __shared__ double Lm;
+    __shared__ double eigbuf[2][64];
+    const int c0 = a.cur[s];
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK)
+        sed_s[(i / B) * BM + (i % B)] = a.sed[c0][(size_t)s * K * B + i];
+    __syncthreads();
+    // the morphology step's Lipschitz constant, as step_psf_head computes it
+    if (a.approximate_L) {
+        if (threadIdx.x == 0) {
+            double LS = 0, l = 0;
+            for (int k = 0; k < K; ++k)
+                for (int b = 0; b < B; ++b) LS += (double)sed_s[k * BM + b] * sed_s[k * BM + b];
+            for (int b = 0; b < B; ++b) l += a.loss_part[s * B + b];
+            const int it_new = a.it[s] + 1;
+            if (it_new > 1 && l > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) LS *= 2;
+            Lm = LS;
+        }
+    } else {
+        for (int i = threadIdx.x; i < B * B; i += SC_BLOCK) {
+            const int b = i / B, b2 = i - b * B;
+            double r = 0;
+            for (int k = 0; k < K; ++k) r += (double)sed_s[k * BM + b] * sed_s[k * BM + b2];
+            ATA[b * BM + b2] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x < SC_WAVE) {
+            double l = 0;
+            if (B <= 4) { if (threadIdx.x == 0) l = lambda_max_charpoly4(ATA, B, BM); }
+            else l = wave_lambda_max8(ATA, B, BM, eigbuf);
+            if (threadIdx.x == 0) Lm = l;
+        }
+    }
+    __syncthreads();
+    const float step_morph = 1.0f / (float)Lm;
+    // the SEDs as scalars (SGPRs): hoisted LDS reads would hold KM * BM vector registers across the loop
+    float sk[KM][BM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b)
+            sk[k][b] = (k < K && b < B) ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sed_s[k * BM + b]))) : 0.f;
+    float dsed[KM][BM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b) dsed[k][b] = 0.f;
+    const int HW4 = HW >> 2;
+    const float4 *mor = reinterpret_cast<const float4 *>(a.morph[c0] + (size_t)s * K * HW);
+    float4 *mout = reinterpret_cast<float4 *>(a.morph[1 - c0] + (size_t)s * K * HW);
+    const float4 *G = reinterpret_cast<const float4 *>(a.real + (size_t)s * B * HW);
+    const int g_end = min(HW4, (tile + 1) * (SC_TILE_PIX >> 2));
+#pragma unroll 1
+    for (int g = tile * (SC_TILE_PIX >> 2) + threadIdx.x; g < g_end; g += SC_BLOCK) {
+        float4 gb[BM];
+#pragma unroll
+        for (int b = 0; b < BM; ++b) gb[b] = b < B ? G[(size_t)b * HW4 + g] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < K) {
+                const float4 m = mor[(size_t)k * HW4 + g];
+                float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int b = 0; b < BM; ++b)
+                    if (b < B) {
+                        gm.x += sk[k][b] * gb[b].x; gm.y += sk[k][b] * gb[b].y; gm.z += sk[k][b] * gb[b].z; gm.w += sk[k][b] * gb[b].w;
+                        dsed[k][b] += gb[b].x * m.x; dsed[k][b] += gb[b].y * m.y;
+                        dsed[k][b] += gb[b].z * m.z; dsed[k][b] += gb[b].w * m.w;
+                    }
+                const bool fixed = a.fix_morph && a.fix_morph[(size_t)s * K + k];
+                float4 o;
+                if (a.raw_gradient) o = gm;
+                else if (fixed) o = m;
+                else o = make_float4(m.x - step_morph * gm.x, m.y - step_morph * gm.y, m.z - step_morph * gm.z, m.w - step_morph * gm.w);
+                mout[(size_t)k * HW4 + g] = o;
+            }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int b = 0; b < BM; ++b)
+            if (k < K && b < B) {
+                const double v = wave_sum((double)dsed[k][b]);
+                if (lane == 0) red[wid][k * B + b] = v;
+            }
+    __syncthreads();
+    const int P = n_partials(K, B);
+    double *out = a.partials + ((size_t)s * a.T + tile) * P;
+    for (int i = threadIdx.x; i < K * B; i += SC_BLOCK) {
+        double r = 0;
+#pragma unroll
+        for (int w = 0; w < SC_NWAVES; ++w) r += red[w][i];
+        out[1 + i] = r;
+    }
+    if (threadIdx.x == 0) {
+        double l = 0;
+        if (tile == 0) for (int b = 0; b < B; ++b) l += a.loss_part[s * B + b];
+        out[0] = l;
+    }
+}
+
+// one workgroup per scene: the scalar head of the step (partial sums, Lipschitz constants, SED step, loss record)
+template <int KM, int BM>
+__global__ __launch_bounds__(SC_BLOCK) void k_sed_step(PsfArgs a)
+{
+    const int s = blockIdx.x;
+    if (!a.active[s]) return;
+    __shared__ double tot[1 + KM * BM + KM * (KM + 1) / 2];
+    __shared__ double mat[KM * KM + BM * BM];
+    __shared__ float sed_s[KM * BM];
+    __shared__ float step_s[2];
+    __shared__ double Lc[2];
+    __shared__ double eigbuf[2][2][64];
+    step_psf_head<KM, BM>(a, s, 0, tot, mat, sed_s, step_s, Lc, eigbuf);
+}
+
 // kernel image [B][Py][Px] -> padded, shifted FFT input planes [B][Fy][Fx]
 __global__ void k_psf_pad_kernel(const float *ker, int B, int Py, int Px, int Fy, int Fx, int oky, int okx,
                                  float *out)

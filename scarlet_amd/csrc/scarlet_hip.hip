@@ -48,9 +48,10 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
-                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER", "NO_BOX", "NO_BOX2"};
+                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER", "NO_BOX", "NO_BOX2",
+                                                   "NO_PSF3PASS"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -775,7 +776,7 @@ static int64_t base_workspace_bytes(const scarlet_batch *b)
     const int64_t P = n_partials(b->K, b->B);
     // K > 8 (bigk.h): one scratch plane set [S][B][HW] for G = w^2 (model - image)
     const int64_t resid = b->K > SC_KMAX ? align256(sizeof(float) * (int64_t)b->S * b->B * b->H * b->W) : 0;
-    return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4) + sizeof(int) * (int64_t)b->S * b->K) +
+    return align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4) + sizeof(int) * (2 * (int64_t)b->S * b->K + 64)) +
            resid + gscratch_bytes(b) + kscache_bytes(b) + 256;
 }
 // ---- LDS-resident convolution (fftconv.h): plan = lengths, radices, kernel placement
@@ -888,10 +889,12 @@ static float *ws_resid(const scarlet_batch *b)
 {
     const int64_t P = n_partials(b->K, b->B);
     return (float *)((char *)b->workspace +
-                     align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4) + sizeof(int) * (int64_t)b->S * b->K));
+                     align256(sizeof(double) * ((int64_t)b->S * n_tiles(b) * P + (int64_t)b->S * b->K * 4) + sizeof(int) * (2 * (int64_t)b->S * b->K + 64)));
 }
 // per component: 1 = k_source_update_box left it to the full-frame kernel (behind the convergence sums)
 static int *ws_box_fallback(const scarlet_batch *b) { return (int *)(ws_conv(b) + (size_t)b->S * b->K * 4); }
+// the components the small box left to the large one: list [S * K] + its length (behind the fallback flags)
+static int *ws_box_list(const scarlet_batch *b) { return ws_box_fallback(b) + (size_t)b->S * b->K; }
 
 static float *ws_gscratch(const scarlet_batch *b)
 {
@@ -1018,6 +1021,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
     int rc;
     FftPlan fp;
     const bool lds_path = psf_use_lds(b, &fp);
+    const bool three_pass = lds_path && (b->H * b->W) % 4 == 0 && b->K <= SC_KMAX && !opt(OPT_NO_PSF3PASS);
     if (lds_path) {
         // one kernel: model, render, residual + loss, adjoint -> compact gradient planes G [S][B][H][W] in `real`
         fp.tables = (const float2 *)((char *)b->workspace + l.lds_tables);
@@ -1032,7 +1036,11 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         prof_start(5, st);
         // model planes, compact [S][B][H][W], into `real` (k_psf_model with the geometry of an unpadded plane)
         a.g.Fy = b->H; a.g.Fx = b->W; a.g.Fxh = b->W / 2 + 1; a.g.oy = 0; a.g.ox = 0;
-        if ((b->H * b->W) % 4 == 0)
+        if (three_pass) {
+            // model planes + Gram partials in one pass (psf_path.h, "three-pass form")
+            if (b->K <= 4) hipLaunchKernelGGL((k_psf_model4g<4>), dim3(a.T, a.S), dim3(SC_BLOCK), 0, st, a);
+            else hipLaunchKernelGGL((k_psf_model4g<SC_KMAX>), dim3(a.T, a.S), dim3(SC_BLOCK), 0, st, a);
+        } else if ((b->H * b->W) % 4 == 0)
             hipLaunchKernelGGL(k_psf_model4, dim3(((b->H * b->W) / 4 + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
         else
             hipLaunchKernelGGL(k_psf_model, dim3((b->H * b->W + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
@@ -1080,7 +1088,23 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         HIP_TRY(hipGetLastError());
         return SCARLET_OK;
     }
-    if (lds_path && (b->H * b->W) % 4 == 0) {
+    if (three_pass) {
+        // morphology step + SED-gradient partials in one pass over G, then the per-scene scalar head
+        prof_start(1, st);
+        // (instances by band count: the accumulators of absent bands would cost occupancy)
+        if (b->K <= 4) {
+            if (b->B <= 4) hipLaunchKernelGGL((k_step_psf4f<4, 4>), grid, dim3(SC_BLOCK), 0, st, a);
+            else if (b->B <= 6) hipLaunchKernelGGL((k_step_psf4f<4, 6>), grid, dim3(SC_BLOCK), 0, st, a);
+            else hipLaunchKernelGGL((k_step_psf4f<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+            hipLaunchKernelGGL((k_sed_step<4, SC_BMAX>), dim3(a.S), dim3(SC_BLOCK), 0, st, a);
+        } else {
+            if (b->B <= 4) hipLaunchKernelGGL((k_step_psf4f<SC_KMAX, 4>), grid, dim3(SC_BLOCK), 0, st, a);
+            else if (b->B <= 6) hipLaunchKernelGGL((k_step_psf4f<SC_KMAX, 6>), grid, dim3(SC_BLOCK), 0, st, a);
+            else hipLaunchKernelGGL((k_step_psf4f<SC_KMAX, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
+            hipLaunchKernelGGL((k_sed_step<SC_KMAX, SC_BMAX>), dim3(a.S), dim3(SC_BLOCK), 0, st, a);
+        }
+        prof_stop(st);
+    } else if (lds_path && (b->H * b->W) % 4 == 0) {
         // compact gradient planes: 16 B per lane
         prof_start(0, st);
         if (b->K <= 4) hipLaunchKernelGGL((k_grad_psf4<4, SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a);
@@ -1279,17 +1303,22 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
         const size_t lds1 = sizeof(float) * ub_lds_floats(b->H, b->W, 31), lds2 = sizeof(float) * ub_lds_floats(b->H, b->W, 63);
         long long *dbg = debug_stamps((size_t)b->S * b->K * 16);
         int *fb = ws_box_fallback(b);
+        int *list = ws_box_list(b), *count = list + (size_t)b->S * b->K;
         hipStream_t st = (hipStream_t)stream;
+        const bool second = !opt(OPT_NO_BOX2);
+        if (second) HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), st));
+        // the large box: workgroup i takes list[i]
+        const int listed_grid = b->S * b->K;
         if (b->H <= 128 && b->W <= 128) {
-            if ((rc = allow_lds(k_source_update_box<8, 31>, lds1)) || (rc = allow_lds(k_source_update_box<8, 63>, lds2))) return rc;
-            hipLaunchKernelGGL((k_source_update_box<8, 31>), dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, (const int *)nullptr, fb, dbg);
-            if (!opt(OPT_NO_BOX2))
-                hipLaunchKernelGGL((k_source_update_box<8, 63>), dim3(b->S * b->K), dim3(SC_BLOCK), lds2, st, u, (const int *)fb, fb, (long long *)nullptr);
+            if ((rc = allow_lds(k_source_update_box<8>, lds1)) || (rc = allow_lds(k_source_update_box_listed<8>, lds2))) return rc;
+            hipLaunchKernelGGL((k_source_update_box<8>), dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, fb, second ? list : nullptr, count, dbg);
+            if (second)
+                hipLaunchKernelGGL((k_source_update_box_listed<8>), dim3(listed_grid), dim3(SC_BLOCK), lds2, st, u, fb, (const int *)list, (const int *)count, dbg);
         } else {
-            if ((rc = allow_lds(k_source_update_box<16, 31>, lds1)) || (rc = allow_lds(k_source_update_box<16, 63>, lds2))) return rc;
-            hipLaunchKernelGGL((k_source_update_box<16, 31>), dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, (const int *)nullptr, fb, dbg);
-            if (!opt(OPT_NO_BOX2))
-                hipLaunchKernelGGL((k_source_update_box<16, 63>), dim3(b->S * b->K), dim3(SC_BLOCK), lds2, st, u, (const int *)fb, fb, (long long *)nullptr);
+            if ((rc = allow_lds(k_source_update_box<16>, lds1)) || (rc = allow_lds(k_source_update_box_listed<16>, lds2))) return rc;
+            hipLaunchKernelGGL((k_source_update_box<16>), dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, fb, second ? list : nullptr, count, dbg);
+            if (second)
+                hipLaunchKernelGGL((k_source_update_box_listed<16>), dim3(listed_grid), dim3(SC_BLOCK), lds2, st, u, fb, (const int *)list, (const int *)count, dbg);
         }
         u.only_flagged = fb;
     }

@@ -343,3 +343,37 @@ def test_config3_full_size_properties(scarlet):
     idx = torch.arange(S, device=m.device) % U
     assert torch.equal(m, ms[idx]) and torch.equal(s, ss[idx]) and torch.equal(mse, mses[idx])
     assert bool((mse[:, -1] < mse[:, 0]).all())
+
+
+@pytest.mark.parametrize("K,approx", [(8, False), (3, False), (8, True)])
+def test_three_pass_iteration_equals_four_pass(scarlet, K, approx):
+    """The PSF iteration without the separate reduction pass (model + Gram, convolution, step + SED-gradient
+    sums, scalar head: psf_path.h) keeps every sum's order; what differs from the four-pass form is the
+    compiler's choice of fused / unfused multiply-adds in the two sets of kernels (measured: one SED entry off
+    by one ulp after the first iteration): same iteration counts, values equal to 2e-6 of the array's maximum."""
+    from scarlet_amd import synth, fft as fftmod, _lib
+    B, H, W, S = 5, 128, 128, 3
+    obs_psfs = np.array([synth.gaussian_psf((41, 41), 1.2 + 0.15 * b) for b in range(B)])
+    model_psf = synth.gaussian_psf((41, 41), 0.9)
+    diff = np.asarray(fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                        fftmod.Fourier(model_psf[None].astype(np.float32))).image, dtype=np.float32)
+    scenes = [synth.make_scene(900 + i, B=B, H=H, W=W, K=K, psfs=obs_psfs) for i in range(S)]
+    out = []
+    for four in (1, 0):
+        _lib.set_option("NO_PSF3PASS", four)
+        try:
+            b = scarlet.BlendBatch(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]),
+                                   centroid_weight=model_psf.astype(np.float32))
+            b.set_diff_kernel(diff)
+            b.init_extended(np.ones(B) * 0.1)
+            b.fit(7, e_rel=1e-3, approximate_L=approx)
+            torch.cuda.synchronize()
+            assert int(b.status.abs().sum().item()) == 0
+            out.append((b.morph_current.cpu().numpy().copy(), b.sed_current.cpu().numpy().copy(),
+                        np.array([b.mse(i) for i in range(S)]), b.lipschitz.cpu().numpy().copy(),
+                        b.it.cpu().numpy().copy()))
+        finally:
+            _lib.set_option("NO_PSF3PASS", 0)
+    assert_array_equal(out[0][4], out[1][4])
+    for x, y in zip(out[0][:4], out[1][:4]):
+        assert rel_err(x, y) < 2e-6

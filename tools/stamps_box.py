@@ -6,16 +6,28 @@ import numpy as np, torch
 from scarlet_amd import synth, _lib
 from scarlet_amd.batch import BlendBatch
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
-if cfg == "c3":
+if cfg in ("c3", "c3psf"):
     S, B, H, W, K, kw, first = 2048, 5, 128, 128, 8, {}, 300
 else:
     S, B, H, W, K, kw, first = 64, 6, 256, 256, 30, dict(l0_thresh=0.05), 5000
-scenes = [synth.make_scene(first + i, B=B, H=H, W=W, K=K, min_sep=3 if cfg == "c5" else 4) for i in range(16)]
-reps = (S + 15) // 16
-images = np.tile(np.stack([s["images"] for s in scenes]), (reps, 1, 1, 1))[:S]
-centers = np.tile(np.stack([s["centers"] for s in scenes]), (reps, 1, 1))[:S]
-b = BlendBatch(images, centers, **kw)
-b.init_extended(np.ones(B) * 0.1)
+if cfg == "c3psf":
+    # the bench's config-3 workload (PSF-convolved scenes, difference kernels), 1024 distinct scenes
+    from scarlet_amd import fft as fftmod
+    S, B, H, W, K, kw = 1024, 5, 128, 128, 8, {}
+    obs = np.array([synth.gaussian_psf((41, 41), 1.2 + 0.15 * b) for b in range(B)])
+    model = synth.gaussian_psf((41, 41), 0.9)
+    d = synth.make_batch(0, S, B=B, H=H, W=W, K=K, psfs=obs)
+    b = BlendBatch(d["images"], d["centers"], centroid_weight=model.astype(np.float32))
+    diff = fftmod.match_psfs(fftmod.Fourier(obs.astype(np.float32)), fftmod.Fourier(model[None].astype(np.float32))).image
+    b.set_diff_kernel(np.asarray(diff, dtype=np.float32))
+    b.init_extended(np.ones(B) * 0.1, sed_scale=(model.max() / obs.max(axis=(1, 2))).astype(np.float32))
+else:
+    scenes = [synth.make_scene(first + i, B=B, H=H, W=W, K=K, min_sep=3 if cfg == "c5" else 4) for i in range(16)]
+    reps = (S + 15) // 16
+    images = np.tile(np.stack([s["images"] for s in scenes]), (reps, 1, 1, 1))[:S]
+    centers = np.tile(np.stack([s["centers"] for s in scenes]), (reps, 1, 1))[:S]
+    b = BlendBatch(images, centers, **kw)
+    b.init_extended(np.ones(B) * 0.1)
 for its in (3, 8):
     b.fit(its, e_rel=0, check_every=0)
     torch.cuda.synchronize()
@@ -28,6 +40,25 @@ for its in (3, 8):
     print("after %d more iterations: %d components, completed in the box %d, left to the full path %d" % (its, len(st), ok.sum(), fb.sum()))
     ls = st[ok, 8]
     print("   stop level percentiles 10/50/90/99/max:", np.percentile(ls, [10, 50, 90, 99, 100]))
+    big = ok & (st[:, 9] == 63)
+    print("   completed in the 127 x 127 box: %d (%.1f %%), their stop levels 10/50/90/max: %s, cycles per component %.0f"
+          % (big.sum(), 100.0 * big.sum() / len(st), np.percentile(st[big, 8], [10, 50, 90, 100]) if big.any() else "-",
+             (st[big, 7] - st[big, 0]).mean() if big.any() else 0))
+    if big.any():
+        t0 = st[big, 0].min()
+        dur = st[big, 7] - st[big, 0]
+        print("      127-box kernel timeline (cycles after the first start): starts 50/90/100 %%: %s, last end %d; per-component cycles 50/90/99/max: %s"
+              % (np.percentile(st[big, 0] - t0, [50, 90, 100]).astype(int), (st[big, 7] - t0).max(), np.percentile(dur, [50, 90, 99, 100]).astype(int)))
+        # (the cycle counters of the eight XCDs are not synchronised: timelines per XCD = workgroup index mod 8)
+        for x in range(8):
+            sel = big & (np.arange(len(st)) % 8 == x)
+            if sel.any():
+                span = (st[sel, 7].max() - st[sel, 0].min())
+                print("      XCD %d: %d components, makespan %d cycles, mean concurrency %.1f workgroups" % (x, sel.sum(), span, (st[sel, 7] - st[sel, 0]).sum() / span))
+        for i, nm in enumerate(["max_pixel(+centroid)", "box load + vectors", "GEMM1 (X through LDS)", "rank-1 z", "GEMM2 + epilogue", "sweep", "final pass"]):
+            print("      127-box %-24s %8.0f" % (nm, (st[big, i + 1] - st[big, i]).mean()))
+    ok = ok & (st[:, 9] != 63)
+    ls = st[ok, 8]
     names = ["max_pixel(+centroid)", "box load + vectors", "GEMM1 (X through LDS)", "rank-1 z", "GEMM2 + epilogue", "sweep", "final pass"]
     tot = (st[ok, 7] - st[ok, 0]).mean()
     print("   total cycles per component %.0f" % tot)
