@@ -269,7 +269,11 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_lipschitz(GradArgs a)
 }
 
 // ---- pass 4: d loss / d sed partials and the morphology step for one chunk of components
-__global__ __launch_bounds__(SC_BLOCK) void k_bigk_step(GradArgs a, const float *resid)
+// BM: bands the instance is built for (B <= BM).  The chunk's SEDs are scalars (SGPRs) and the accumulators of
+// absent bands do not exist: ~140 VGPRs (three waves per SIMD) instead of the 304 (one wave) of the first form,
+// which held every SED in a vector register across the loop -- a streaming pass needs the waves.
+template <int BM>
+__global__ __launch_bounds__(SC_BLOCK, 2) void k_bigk_step(GradArgs a, const float *resid)
 {
     const int s = blockIdx.z, tile = blockIdx.x, ch = blockIdx.y;
     if (!a.active[s]) return;
@@ -292,7 +296,13 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_step(GradArgs a, const float 
         const int k = ch * SC_CHUNK + i;
         fixm[i] = k < K && a.fix_morph && a.fix_morph[(size_t)s * K + k];
     }
-    float acc[64];                          // dsed[i][b], i = component of the chunk
+    float sk[SC_CHUNK][BM];
+#pragma unroll
+    for (int i = 0; i < SC_CHUNK; ++i)
+#pragma unroll
+        for (int b = 0; b < BM; ++b)
+            sk[i][b] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sed_s[i * SC_BMAX + b])));
+    float acc[64];                          // dsed[i][b], i = component of the chunk (b >= BM: stays 0)
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = 0.f;
     const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
@@ -301,9 +311,9 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_step(GradArgs a, const float 
         const float4 *mor4 = reinterpret_cast<const float4 *>(mor), *G4 = reinterpret_cast<const float4 *>(G);
         float4 *mout4 = reinterpret_cast<float4 *>(mout);
         for (int g = tile * (SC_TILE_PIX >> 2) + threadIdx.x; g < g_end; g += SC_BLOCK) {
-            float4 gb[SC_BMAX];
+            float4 gb[BM];
 #pragma unroll
-            for (int b = 0; b < SC_BMAX; ++b) gb[b] = b < B ? G4[(size_t)b * HW4 + g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int b = 0; b < BM; ++b) gb[b] = b < B ? G4[(size_t)b * HW4 + g] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < SC_CHUNK; ++i) {
                 const int k = ch * SC_CHUNK + i;
@@ -311,12 +321,11 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_step(GradArgs a, const float 
                     const float4 m = mor4[(size_t)k * HW4 + g];
                     float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int b = 0; b < SC_BMAX; ++b) {
+                    for (int b = 0; b < BM; ++b) {
                         float r = acc[i * SC_BMAX + b];
                         r += gb[b].x * m.x; r += gb[b].y * m.y; r += gb[b].z * m.z; r += gb[b].w * m.w;
                         acc[i * SC_BMAX + b] = r;
-                        const float sk = sed_s[i * SC_BMAX + b];
-                        gm.x += sk * gb[b].x; gm.y += sk * gb[b].y; gm.z += sk * gb[b].z; gm.w += sk * gb[b].w;
+                        gm.x += sk[i][b] * gb[b].x; gm.y += sk[i][b] * gb[b].y; gm.z += sk[i][b] * gb[b].z; gm.w += sk[i][b] * gb[b].w;
                     }
                     float4 o;
                     if (a.raw_gradient) o = gm;
@@ -328,9 +337,9 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_step(GradArgs a, const float 
         }
     } else
     for (int p = tile * SC_TILE_PIX + threadIdx.x; p < p_end; p += SC_BLOCK) {
-        float gb[SC_BMAX];
+        float gb[BM];
 #pragma unroll
-        for (int b = 0; b < SC_BMAX; ++b) gb[b] = b < B ? G[(size_t)b * HW + p] : 0.f;
+        for (int b = 0; b < BM; ++b) gb[b] = b < B ? G[(size_t)b * HW + p] : 0.f;
 #pragma unroll
         for (int i = 0; i < SC_CHUNK; ++i) {
             const int k = ch * SC_CHUNK + i;
@@ -338,9 +347,9 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_step(GradArgs a, const float 
                 const float m = mor[(size_t)k * HW + p];
                 float gm = 0.f;
 #pragma unroll
-                for (int b = 0; b < SC_BMAX; ++b) {
+                for (int b = 0; b < BM; ++b) {
                     acc[i * SC_BMAX + b] += gb[b] * m;
-                    gm += sed_s[i * SC_BMAX + b] * gb[b];
+                    gm += sk[i][b] * gb[b];
                 }
                 mout[(size_t)k * HW + p] = a.raw_gradient ? gm : (fixm[i] ? m : m - step_morph * gm);
             }

@@ -997,6 +997,15 @@ extern "C" int scarlet_batch_prepare_psf(scarlet_batch *b, void *stream)
     return SCARLET_OK;
 }
 
+// k_bigk_step by band count (the accumulators of absent bands would cost occupancy)
+static void launch_bigk_step(const GradArgs &a, int nch, const float *resid, hipStream_t st)
+{
+    const dim3 grid(a.T, nch, a.S);
+    if (a.B <= 4) hipLaunchKernelGGL((k_bigk_step<4>), grid, dim3(SC_BLOCK), 0, st, a, resid);
+    else if (a.B <= 6) hipLaunchKernelGGL((k_bigk_step<6>), grid, dim3(SC_BLOCK), 0, st, a, resid);
+    else hipLaunchKernelGGL((k_bigk_step<SC_BMAX>), grid, dim3(SC_BLOCK), 0, st, a, resid);
+}
+
 static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradient, void *stream)
 {
     const PsfGeom g = psf_geom(b->H, b->W, b->psf_h, b->psf_w);
@@ -1082,7 +1091,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         hipLaunchKernelGGL(k_bigk_gram, dim3(ga.T, nch * (nch + 1) / 2, ga.S), dim3(SC_BLOCK), 0, st, ga);
         hipLaunchKernelGGL(k_bigk_lipschitz, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga);
         prof_stop(st); prof_start(1, st);
-        hipLaunchKernelGGL(k_bigk_step, dim3(ga.T, nch, ga.S), dim3(SC_BLOCK), 0, st, ga, (const float *)resid);
+        launch_bigk_step(ga, nch, resid, st);
         hipLaunchKernelGGL(k_bigk_sed, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga);
         prof_stop(st);
         HIP_TRY(hipGetLastError());
@@ -1239,7 +1248,7 @@ static int backward_impl(scarlet_batch *b, int approximate_L, int raw_gradient, 
         hipLaunchKernelGGL(k_bigk_gram, dim3(a.T, nch * (nch + 1) / 2, a.S), dim3(SC_BLOCK), 0, st, a);
         hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
         prof_stop(st); prof_start(1, st);
-        hipLaunchKernelGGL(k_bigk_step, dim3(a.T, nch, a.S), dim3(SC_BLOCK), 0, st, a, (const float *)resid);
+        launch_bigk_step(a, nch, resid, st);
         hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
         prof_stop(st);
         HIP_TRY(hipGetLastError());
