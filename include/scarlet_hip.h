@@ -27,6 +27,10 @@
  * FFT lengths (filled once per device), the hipFFT plan cache of the large-frame fallback of the
  * PSF path, the diagnostic switches of scarlet_set_option(), and the event recorder of
  * scarlet_profile_begin/end (one profiled region at a time, whichever batch launches inside it).
+ * Per calling thread (and device) it keeps one further stream and three events: with more than eight
+ * components per scene the Gram matrix and its eigenvalue run beside the morphology step, forked from and
+ * joined back into the caller's stream by events -- to the caller the entry point stays asynchronous on
+ * the stream it passed, and a stream capture records both branches.
  * Set-up and host-pointer entry points that need temporary device memory release it on every
  * exit path, error paths included.
  */
@@ -73,7 +77,7 @@ extern "C" {
 const char *scarlet_version(void);
 const char *scarlet_last_error(void);
 /* Diagnostic switches: NO_EXACT, NO_KSCACHE, FUSED_V1, NO_FUSED, FORCE_BLOCK_UPDATE,
- * NO_HYBRID_SWEEP, PAD_LDS, STAMPS, PSF_HIPFFT, NO_PERSIST, NO_STAGGER, NO_BOX, NO_BOX2, NO_PSF3PASS.  Each starts from the environment variable
+ * NO_HYBRID_SWEEP, PAD_LDS, STAMPS, PSF_HIPFFT, NO_PERSIST, NO_STAGGER, NO_BOX, NO_BOX2, NO_PSF3PASS, NO_SIDE_STREAM.  Each starts from the environment variable
  * SCARLET_<NAME>, read once at first use; afterwards only this call changes it.  Returns the
  * previous value (0 / 1) or SCARLET_E_ARG for an unknown name.  None changes results beyond
  * float32 rounding. */

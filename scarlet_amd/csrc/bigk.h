@@ -163,7 +163,9 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_gram(GradArgs a)
 // One WORKGROUP per scene: the 30 dependent 32 x 32 x 32 float64 products are the whole cost of this pass (a
 // single wave took 0.24 ms for BASELINE config 5 whatever the number of scenes); four waves share each product,
 // a thread owns a 2 x 2 block, operands are read from LDS four k at a time.
-__global__ __launch_bounds__(SC_BLOCK) void k_bigk_lipschitz(GradArgs a)
+// `sed_only`: lambda_max(A^T A) comes from k_bigk_lmorph (the morphology step waits for that one only; this
+// kernel then runs beside the step on a second stream, scarlet_hip.hip) and lipschitz[2 s + 1] is not written here.
+__global__ __launch_bounds__(SC_BLOCK) void k_bigk_lipschitz(GradArgs a, int sed_only)
 {
     const int s = blockIdx.x;
     if (!a.active[s]) return;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_lipschitz(GradArgs a)
             const double num = wave_sum(v * gv), den = wave_sum(v * v);
             L_sed = num / den;
             // ---- lambda_max(A^T A): the smaller of the two Gram matrices of the SED matrix (<= 8 x 8)
-            const int n = K < B ? K : B;
+            const int n = sed_only ? 0 : (K < B ? K : B);
             for (int i = lane; i < n * n; i += SC_WAVE) {
                 const int x = i / n, y = i - x * n;
                 double r = 0;
@@ -258,14 +260,52 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_lipschitz(GradArgs a)
                 ata[x * n + y] = r;
             }
             wave_sync();
-            if (lane == 0) L_morph = jacobi_lambda_max(ata, n, n);
+            if (lane == 0 && !sed_only) L_morph = jacobi_lambda_max(ata, n, n);
         }
     }
     if (tid == 0) {
         if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
         a.lipschitz[2 * s] = L_sed;
-        a.lipschitz[2 * s + 1] = L_morph;
+        if (!sed_only) a.lipschitz[2 * s + 1] = L_morph;
     }
+}
+
+// lambda_max(A^T A) alone (blend.py:205-218), one wave per scene: all the morphology step needs.  Power iteration
+// by repeated squaring on the wave (wave_lambda_max8) instead of the single-lane Jacobi above: ~10 k cycles.
+__global__ __launch_bounds__(SC_WAVE) void k_bigk_lmorph(GradArgs a)
+{
+    const int s = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, P = n_partials(K, B), lane = threadIdx.x;
+    __shared__ double ata[SC_BMAX * SC_BMAX];
+    __shared__ float sed_s[SC_KBIG * SC_BMAX];
+    __shared__ double buf[2][64];
+    const int c0 = a.cur[s];
+    for (int i = lane; i < K * B; i += SC_WAVE)
+        sed_s[(i / B) * SC_BMAX + (i % B)] = a.sed[c0][(size_t)s * K * B + i];
+    wave_sync();
+    double L_morph;
+    if (a.approximate_L) {
+        double LS = 0, loss = 0;
+        for (int i = lane; i < K * B; i += SC_WAVE) { const float v = sed_s[(i / B) * SC_BMAX + (i % B)]; LS += (double)v * v; }
+        LS = wave_sum(LS);
+        for (int t = 0; t < a.T; ++t) loss += a.partials[((size_t)s * a.T + t) * P];
+        const int it_new = a.it[s] + 1;
+        if (it_new > 1 && loss > a.mse[(size_t)s * a.mse_capacity + it_new - 2]) LS *= 2;
+        L_morph = LS;
+    } else {
+        const int n = K < B ? K : B;
+        for (int i = lane; i < n * n; i += SC_WAVE) {
+            const int x = i / n, y = i - x * n;
+            double r = 0;
+            if (K < B) for (int b = 0; b < B; ++b) r += (double)sed_s[x * SC_BMAX + b] * sed_s[y * SC_BMAX + b];
+            else       for (int k = 0; k < K; ++k) r += (double)sed_s[k * SC_BMAX + x] * sed_s[k * SC_BMAX + y];
+            ata[x * n + y] = r;
+        }
+        wave_sync();
+        L_morph = wave_lambda_max8(ata, n, n, buf);
+    }
+    if (lane == 0) a.lipschitz[2 * s + 1] = L_morph;
 }
 
 // ---- pass 4: d loss / d sed partials and the morphology step for one chunk of components

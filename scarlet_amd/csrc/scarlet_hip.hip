@@ -48,10 +48,10 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
                                                    "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER", "NO_BOX", "NO_BOX2",
-                                                   "NO_PSF3PASS"};
+                                                   "NO_PSF3PASS", "NO_SIDE_STREAM"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -997,6 +997,27 @@ extern "C" int scarlet_batch_prepare_psf(scarlet_batch *b, void *stream)
     return SCARLET_OK;
 }
 
+// A second stream per calling thread for work that is off an iteration's critical path (fork / join by events, so a
+// caller capturing its stream into a hipGraph captures both branches).
+struct SideStream { hipStream_t st; hipEvent_t ev[3]; int device; };
+static int side_stream(SideStream **out)
+{
+    static thread_local SideStream t_side[16];          // one per device this thread has used
+    static thread_local int t_n = 0;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    for (int i = 0; i < t_n; ++i)
+        if (t_side[i].device == dev) { *out = &t_side[i]; return SCARLET_OK; }
+    if (t_n == 16) { *out = nullptr; return SCARLET_OK; }   // (more devices than that in one thread: no second stream)
+    SideStream &n = t_side[t_n];
+    HIP_TRY(hipStreamCreateWithFlags(&n.st, hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreateWithFlags(&n.ev[i], hipEventDisableTiming));
+    n.device = dev;
+    ++t_n;
+    *out = &n;
+    return SCARLET_OK;
+}
+
 // k_bigk_step by band count (the accumulators of absent bands would cost occupancy)
 static void launch_bigk_step(const GradArgs &a, int nch, const float *resid, hipStream_t st)
 {
@@ -1089,7 +1110,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         hipLaunchKernelGGL(k_bigk_loss_from_planes, dim3((b->S + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0, st, ga,
                            (const double *)a.loss_part);
         hipLaunchKernelGGL(k_bigk_gram, dim3(ga.T, nch * (nch + 1) / 2, ga.S), dim3(SC_BLOCK), 0, st, ga);
-        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga);
+        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga, 0);
         prof_stop(st); prof_start(1, st);
         launch_bigk_step(ga, nch, resid, st);
         hipLaunchKernelGGL(k_bigk_sed, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga);
@@ -1243,10 +1264,35 @@ static int backward_impl(scarlet_batch *b, int approximate_L, int raw_gradient, 
         // many components per scene: passes over chunks of eight (bigk.h)
         const int nch = (b->K + SC_CHUNK - 1) / SC_CHUNK;
         float *resid = ws_resid(b);
+        SideStream *side = nullptr;
+        if (!opt(OPT_NO_SIDE_STREAM) && (rc = side_stream(&side))) return rc;
+        if (side) {
+            // The morphology step needs the residual planes and lambda_max(A^T A) only; the Gram matrix S S^T and
+            // its largest eigenvalue (for the SED step) run beside it on a second stream:
+            //   stream : resid . lmorph . step ............ (join) sed
+            //   side   : gram ......... (after resid: loss) lipschitz
+            HIP_TRY(hipEventRecord(side->ev[0], st));
+            HIP_TRY(hipStreamWaitEvent(side->st, side->ev[0], 0));
+            hipLaunchKernelGGL(k_bigk_gram, dim3(a.T, nch * (nch + 1) / 2, a.S), dim3(SC_BLOCK), 0, side->st, a);
+            prof_start(0, st);
+            hipLaunchKernelGGL(k_bigk_resid, grid, dim3(SC_BLOCK), 0, st, a, resid);
+            HIP_TRY(hipEventRecord(side->ev[1], st));
+            HIP_TRY(hipStreamWaitEvent(side->st, side->ev[1], 0));
+            hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_BLOCK), 0, side->st, a, 1);
+            HIP_TRY(hipEventRecord(side->ev[2], side->st));
+            hipLaunchKernelGGL(k_bigk_lmorph, dim3(a.S), dim3(SC_WAVE), 0, st, a);
+            prof_stop(st); prof_start(1, st);
+            launch_bigk_step(a, nch, resid, st);
+            HIP_TRY(hipStreamWaitEvent(st, side->ev[2], 0));
+            hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
+            prof_stop(st);
+            HIP_TRY(hipGetLastError());
+            return SCARLET_OK;
+        }
         prof_start(0, st);
         hipLaunchKernelGGL(k_bigk_resid, grid, dim3(SC_BLOCK), 0, st, a, resid);
         hipLaunchKernelGGL(k_bigk_gram, dim3(a.T, nch * (nch + 1) / 2, a.S), dim3(SC_BLOCK), 0, st, a);
-        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
+        hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_BLOCK), 0, st, a, 0);
         prof_stop(st); prof_start(1, st);
         launch_bigk_step(a, nch, resid, st);
         hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
