@@ -153,6 +153,76 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_gram(GradArgs a)
     }
 }
 
+// ---- pass 2 on the matrix cores: the whole K x K Gram block of a tile in ONE pass over the morphologies.
+// S S^T is a GEMM whose reduction index is the pixel: v_mfma_f32_32x32x2_f32 takes A[i][k] = B[k][i] =
+// m_i(pixel k) from the SAME register -- lane (component i = lane & 31, half h = lane >> 5) loads 16 consecutive
+// pixels of its component (4 x 16 B; the two halves of a component make a 128-byte line) and issues one MFMA per
+// pixel pair.  Every morphology value is loaded once instead of once per chunk pair (4 x for K = 30), and the 64
+// accumulators per thread of the chunk-pair form become 16.  float32 accumulation inside the MFMA is flushed to
+// float64 every 256 pixels per wave (the chunk-pair form sums 64 float32 products per thread before its float64
+// tree: the same class of rounding).  HW % 4 == 0, K <= 32.  grid (T, S).
+typedef float bigk_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(SC_BLOCK) void k_bigk_gram_mfma(GradArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.HW;
+    __shared__ double red[SC_NWAVES][16][SC_WAVE];                 // 32 KB
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, comp = lane & 31, half = lane >> 5;
+    const float *mor = a.morph[a.cur[s]] + (size_t)s * K * HW + (size_t)(comp < K ? comp : 0) * HW;
+    const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    constexpr int WPIX = SC_TILE_PIX / SC_NWAVES, NBATCH = WPIX / 32;   // 1024 pixels per wave in 32 batches of 32
+    const int p0 = tile * SC_TILE_PIX + wid * WPIX + half * 16;
+    auto load = [&](int j, float4 (&v)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + j * 32 + 4 * q;
+            v[q] = (comp < K && p < p_end) ? *reinterpret_cast<const float4 *>(mor + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    double accd[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accd[r] = 0.0;
+    bigk_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 cur[4], nxt[4];
+    load(0, cur);
+#pragma unroll 1
+    for (int j = 0; j < NBATCH; ++j) {
+        if (j + 1 < NBATCH) load(j + 1, nxt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].x, cur[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].y, cur[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].z, cur[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].w, cur[q].w, acc, 0, 0, 0);
+        }
+        if ((j & 7) == 7) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accd[r] += (double)acc[r]; acc[r] = 0.f; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+    }
+    // C layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid][r][lane] = accd[r];
+    __syncthreads();
+    const int P = n_partials(K, B);
+    double *out = a.partials + ((size_t)s * a.T + tile) * P + 1 + K * B;
+    for (int e = threadIdx.x; e < 16 * SC_WAVE; e += SC_BLOCK) {
+        const int r = e >> 6, l = e & 63;
+        const int col = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (row <= col && col < K) {
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < SC_NWAVES; ++w) v += red[w][r][l];
+            out[row * K - (row * (row - 1)) / 2 + (col - row)] = v;
+        }
+    }
+}
+
 // ---- pass 3: Lipschitz constants, one wave per scene (blend.py:186-223)
 // lambda_max of the PSD Gram matrix G (n <= 32): M = G / tr G is squared SC_SQUARINGS times
 // (renormalised by its trace each time), which leaves u1 u1^T up to terms (lambda_i /

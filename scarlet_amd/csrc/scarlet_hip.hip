@@ -48,10 +48,10 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_NO_GRAM_MFMA, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
                                                    "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER", "NO_BOX", "NO_BOX2",
-                                                   "NO_PSF3PASS", "NO_SIDE_STREAM"};
+                                                   "NO_PSF3PASS", "NO_SIDE_STREAM", "NO_GRAM_MFMA"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -1018,6 +1018,15 @@ static int side_stream(SideStream **out)
     return SCARLET_OK;
 }
 
+// the Gram partials of the many-component path: one MFMA pass when the planes allow 16-byte loads
+static void launch_bigk_gram(const GradArgs &a, int nch, hipStream_t st)
+{
+    if ((a.HW & 3) == 0 && !opt(OPT_NO_GRAM_MFMA))
+        hipLaunchKernelGGL(k_bigk_gram_mfma, dim3(a.T, a.S), dim3(SC_BLOCK), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_bigk_gram, dim3(a.T, nch * (nch + 1) / 2, a.S), dim3(SC_BLOCK), 0, st, a);
+}
+
 // k_bigk_step by band count (the accumulators of absent bands would cost occupancy)
 static void launch_bigk_step(const GradArgs &a, int nch, const float *resid, hipStream_t st)
 {
@@ -1109,7 +1118,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
                                (const float *)a.real, planes, b->H, b->W, g.Fy, g.Fx, g.oy, g.ox, resid);
         hipLaunchKernelGGL(k_bigk_loss_from_planes, dim3((b->S + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0, st, ga,
                            (const double *)a.loss_part);
-        hipLaunchKernelGGL(k_bigk_gram, dim3(ga.T, nch * (nch + 1) / 2, ga.S), dim3(SC_BLOCK), 0, st, ga);
+        launch_bigk_gram(ga, nch, st);
         hipLaunchKernelGGL(k_bigk_lipschitz, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga, 0);
         prof_stop(st); prof_start(1, st);
         launch_bigk_step(ga, nch, resid, st);
@@ -1273,7 +1282,7 @@ static int backward_impl(scarlet_batch *b, int approximate_L, int raw_gradient, 
             //   side   : gram ......... (after resid: loss) lipschitz
             HIP_TRY(hipEventRecord(side->ev[0], st));
             HIP_TRY(hipStreamWaitEvent(side->st, side->ev[0], 0));
-            hipLaunchKernelGGL(k_bigk_gram, dim3(a.T, nch * (nch + 1) / 2, a.S), dim3(SC_BLOCK), 0, side->st, a);
+            launch_bigk_gram(a, nch, side->st);
             prof_start(0, st);
             hipLaunchKernelGGL(k_bigk_resid, grid, dim3(SC_BLOCK), 0, st, a, resid);
             HIP_TRY(hipEventRecord(side->ev[1], st));
@@ -1291,7 +1300,7 @@ static int backward_impl(scarlet_batch *b, int approximate_L, int raw_gradient, 
         }
         prof_start(0, st);
         hipLaunchKernelGGL(k_bigk_resid, grid, dim3(SC_BLOCK), 0, st, a, resid);
-        hipLaunchKernelGGL(k_bigk_gram, dim3(a.T, nch * (nch + 1) / 2, a.S), dim3(SC_BLOCK), 0, st, a);
+        launch_bigk_gram(a, nch, st);
         hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_BLOCK), 0, st, a, 0);
         prof_stop(st); prof_start(1, st);
         launch_bigk_step(a, nch, resid, st);
