@@ -223,6 +223,153 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_gram_mfma(GradArgs a)
     }
 }
 
+// ---- passes 1 + 4 in ONE pass over the morphologies, on the matrix cores (exact Lipschitz constants, HW % 64 == 0).
+// Everything the gradient step does at a pixel needs that pixel only:
+//     model_b = sum_k sed[k][b] m_k        G_b = w^2 (model_b - image_b)        m_k <- m_k - step sum_b sed[k][b] G_b
+// so the residual planes need not exist in memory: a wave takes 32 consecutive pixels and runs three small GEMMs on
+// v_mfma_f32_32x32x2_f32 whose operand / result layouts chain without moving data between lanes:
+//   model (bands x pixels) = sed^T (bands x comps) . M (comps x pixels), 16 steps of two components.  Lane (pixel p,
+//       half h) supplies at step t the component kappa(t, h) = (t & 3) + 8 (t >> 2) + 4 h -- exactly the row that
+//       register t of a 32 x 32 RESULT holds in that lane --, and receives the model of bands 4 h .. 4 h + 3 at its
+//       pixel in result registers 0 .. 3;
+//   gm (comps x pixels) = sed (comps x bands) . G (bands x pixels), 4 steps of two bands: at step t the halves supply
+//       bands t and 4 + t, which are the G values the lane has just computed; result register t is the gradient of
+//       component kappa(t, h) at the lane's pixel -- next to m_kappa(t, h), loaded for the first product;
+//   dsed (comps x bands) = M (comps x pixels) . G^T (pixels x bands): the reduction runs over pixels, the lanes must
+//       hold components: the 32 x 32 tile of M and the 8 x 32 tile of G go through LDS once (wave-private).
+// Against k_bigk_resid + k_bigk_step: no G planes (B written + 4 B read per chunk), the morphologies read once instead
+// of twice.  The Gram matrix stays with k_bigk_gram_mfma on the second stream.  grid (T, S), four waves of 1024 pixels.
+__global__ __launch_bounds__(SC_BLOCK, 2) void k_bigk_fused(GradArgs a)
+{
+    const int s = blockIdx.y, tile = blockIdx.x;
+    if (!a.active[s]) return;
+    const int K = a.K, B = a.B, HW = a.HW;
+    // A wave takes 64 consecutive pixels per trip as TWO interleaved tiles of 32 (lane p holds pixels 2 p and 2 p + 1:
+    // 8-byte loads and stores, and two independent MFMA chains in every product)
+    constexpr int LDT = 68;                                             // row stride of the transposed tiles (64 + 4)
+    __shared__ __align__(16) float Mt[SC_NWAVES][32][LDT];
+    __shared__ __align__(16) float Gt[SC_NWAVES][8][LDT];
+    __shared__ double dred[SC_NWAVES][256];
+    __shared__ double red[SC_NWAVES];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, p = lane & 31, h = lane >> 5;
+    const int c0 = a.cur[s];
+    const float *sed = a.sed[c0] + (size_t)s * K * B;
+    const float step_morph = 1.0f / (float)a.lipschitz[2 * s + 1];
+    // operand constants: sed^T for the model (row = band = lane & 31, slot h <-> component kappa(t, h)) and sed for the
+    // gradient (row = component = lane & 31, slot h <-> band 4 h + t)
+    float asedT[16], ased[4];
+    unsigned fixmask = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int kap = (t & 3) + 8 * (t >> 2) + 4 * h;
+        asedT[t] = (kap < K && p < B) ? sed[kap * B + p] : 0.f;
+        if (kap < K && a.fix_morph && a.fix_morph[(size_t)s * K + kap]) fixmask |= 1u << t;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ased[t] = (p < K && 4 * h + t < B) ? sed[p * B + 4 * h + t] : 0.f;
+    const float *mor = a.morph[c0] + (size_t)s * K * HW;
+    float *mout = a.morph[1 - c0] + (size_t)s * K * HW;
+    const float *img = a.images + (size_t)s * B * HW;
+    const float *wgt = a.weights ? a.weights + (size_t)s * B * HW : nullptr;
+    const int p_end = min(HW, (tile + 1) * SC_TILE_PIX);
+    constexpr int WPIX = SC_TILE_PIX / SC_NWAVES, NTRIP = WPIX / 64;
+    const int pw = tile * SC_TILE_PIX + wid * WPIX;
+    double loss = 0;
+    bigk_f32x16 accD0, accD1;                                           // dsed, float32 over the wave's 1024 pixels
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accD0[r] = 0.f; accD1[r] = 0.f; }
+#pragma unroll 1
+    for (int j = 0; j < NTRIP; ++j) {
+        if (pw + j * 64 >= p_end) break;                               // (uniform: tiles end on multiples of 64)
+        const int px = pw + j * 64 + 2 * p;
+        float mA[16], mB[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int kap = (t & 3) + 8 * (t >> 2) + 4 * h;
+            const float2 v = kap < K ? *reinterpret_cast<const float2 *>(mor + (size_t)kap * HW + px) : make_float2(0.f, 0.f);
+            mA[t] = v.x; mB[t] = v.y;
+        }
+        float2 im[4], w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = 4 * h + r;
+            im[r] = b < B ? *reinterpret_cast<const float2 *>(img + (size_t)b * HW + px) : make_float2(0.f, 0.f);
+            w[r] = b < B ? (wgt ? *reinterpret_cast<const float2 *>(wgt + (size_t)b * HW + px) : make_float2(a.weight_scalar, a.weight_scalar))
+                         : make_float2(0.f, 0.f);
+        }
+        bigk_f32x16 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(asedT[t], mA[t], accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(asedT[t], mB[t], accB, 0, 0, 0);
+        }
+        float gA[4], gB[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dA = w[r].x * (accA[r] - im[r].x), dB = w[r].y * (accB[r] - im[r].y);   // (bands >= B: w = 0)
+            loss += (double)dA * (double)dA; loss += (double)dB * (double)dB;
+            gA[r] = w[r].x * dA; gB[r] = w[r].y * dB;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(ased[t], gA[t], accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(ased[t], gB[t], accB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int kap = (t & 3) + 8 * (t >> 2) + 4 * h;
+            const bool fx = (fixmask >> t) & 1u;
+            const float oA = a.raw_gradient ? accA[t] : (fx ? mA[t] : mA[t] - step_morph * accA[t]);
+            const float oB = a.raw_gradient ? accB[t] : (fx ? mB[t] : mB[t] - step_morph * accB[t]);
+            if (kap < K) *reinterpret_cast<float2 *>(mout + (size_t)kap * HW + px) = make_float2(oA, oB);
+            *reinterpret_cast<float2 *>(&Mt[wid][kap][2 * p]) = make_float2(mA[t], mB[t]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float2 *>(&Gt[wid][4 * h + r][2 * p]) = make_float2(gA[r], gB[r]);
+        wave_sync();
+        // dsed: lane (row lane & 31, half h) takes pixels 32 h .. 32 h + 31 of its row, two chains of 16 pixel pairs
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float am[16], bg[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(&Mt[wid][p][32 * h + 16 * half + 4 * q]);
+                am[4 * q] = v.x; am[4 * q + 1] = v.y; am[4 * q + 2] = v.z; am[4 * q + 3] = v.w;
+                const float4 u = p < 8 ? *reinterpret_cast<const float4 *>(&Gt[wid][p & 7][32 * h + 16 * half + 4 * q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bg[4 * q] = u.x; bg[4 * q + 1] = u.y; bg[4 * q + 2] = u.z; bg[4 * q + 3] = u.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                accD0 = __builtin_amdgcn_mfma_f32_32x32x2f32(am[q], bg[q], accD0, 0, 0, 0);
+                accD1 = __builtin_amdgcn_mfma_f32_32x32x2f32(am[q + 1], bg[q + 1], accD1, 0, 0, 0);
+            }
+        }
+        wave_sync();
+    }
+    // dsed: result column = band = lane & 31 (< 8 used), row = component (r & 3) + 8 (r >> 2) + 4 h
+    if (p < 8) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dred[wid][((r & 3) + 8 * (r >> 2) + 4 * h) * 8 + p] = (double)accD0[r] + (double)accD1[r];
+    }
+    loss = block_sum(0.5 * loss, red);                                  // (synchronises: dred is complete after it)
+    const int P = n_partials(K, B);
+    double *out = a.partials + ((size_t)s * a.T + tile) * P;
+    if (threadIdx.x == 0) out[0] = loss;
+    for (int e = threadIdx.x; e < 256; e += SC_BLOCK) {
+        const int k = e >> 3, b = e & 7;
+        if (k < K && b < B) {
+            double v = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < SC_NWAVES; ++w2) v += dred[w2][e];
+            out[1 + k * B + b] = v;
+        }
+    }
+}
+
 // ---- pass 3: Lipschitz constants, one wave per scene (blend.py:186-223)
 // lambda_max of the PSD Gram matrix G (n <= 32): M = G / tr G is squared SC_SQUARINGS times
 // (renormalised by its trace each time), which leaves u1 u1^T up to terms (lambda_i /
@@ -233,7 +380,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_gram_mfma(GradArgs a)
 // One WORKGROUP per scene: the 30 dependent 32 x 32 x 32 float64 products are the whole cost of this pass (a
 // single wave took 0.24 ms for BASELINE config 5 whatever the number of scenes); four waves share each product,
 // a thread owns a 2 x 2 block, operands are read from LDS four k at a time.
-// `sed_only`: lambda_max(A^T A) comes from k_bigk_lmorph (the morphology step waits for that one only; this
+// `sed_only` = 2: as 1, and the loss partials do not exist yet (exact constants only): no loss record from here.
+// `sed_only` = 1: lambda_max(A^T A) comes from k_bigk_lmorph (the morphology step waits for that one only; this
 // kernel then runs beside the step on a second stream, scarlet_hip.hip) and lipschitz[2 s + 1] is not written here.
 __global__ __launch_bounds__(SC_BLOCK) void k_bigk_lipschitz(GradArgs a, int sed_only)
 {
@@ -261,7 +409,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_lipschitz(GradArgs a, int sed
         Gm[k][k2] = r;
     }
     double loss = 0;
-    if (w0) for (int t = 0; t < a.T; ++t) loss += a.partials[((size_t)s * a.T + t) * P];
+    if (w0 && sed_only != 2) for (int t = 0; t < a.T; ++t) loss += a.partials[((size_t)s * a.T + t) * P];
     __syncthreads();
     double trace = 0;
     if (tid < SC_KBIG) trace = Gm[tid][tid];
@@ -334,7 +482,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_bigk_lipschitz(GradArgs a, int sed
         }
     }
     if (tid == 0) {
-        if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
+        if (sed_only != 2 && it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
         a.lipschitz[2 * s] = L_sed;
         if (!sed_only) a.lipschitz[2 * s + 1] = L_morph;
     }
@@ -473,12 +621,20 @@ __global__ __launch_bounds__(SC_BLOCK, 2) void k_bigk_step(GradArgs a, const flo
 }
 
 // ---- pass 5: SED step (blend.py:91-93)
-__global__ __launch_bounds__(SC_BLOCK) void k_bigk_sed(GradArgs a)
+// `write_mse`: the loss record of the iteration is written here (k_bigk_lipschitz ran with sed_only = 2, before the
+// loss existed)
+__global__ __launch_bounds__(SC_BLOCK) void k_bigk_sed(GradArgs a, int write_mse)
 {
     const int s = blockIdx.x;
     if (!a.active[s]) return;
     const int K = a.K, B = a.B, P = n_partials(K, B);
     const int c0 = a.cur[s];
+    if (write_mse && threadIdx.x == SC_BLOCK - 1) {
+        double loss = 0;
+        for (int t = 0; t < a.T; ++t) loss += a.partials[((size_t)s * a.T + t) * P];
+        const int it_new = a.it[s] + 1;
+        if (it_new <= a.mse_capacity) a.mse[(size_t)s * a.mse_capacity + it_new - 1] = loss;
+    }
     const float step_sed = 1.0f / (float)a.lipschitz[2 * s];
     for (int i = threadIdx.x; i < K * B; i += SC_BLOCK) {
         double g = 0;

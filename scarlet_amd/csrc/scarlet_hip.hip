@@ -48,10 +48,10 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_NO_GRAM_MFMA, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_NO_GRAM_MFMA, OPT_NO_BIGK_FUSED, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
                                                    "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER", "NO_BOX", "NO_BOX2",
-                                                   "NO_PSF3PASS", "NO_SIDE_STREAM", "NO_GRAM_MFMA"};
+                                                   "NO_PSF3PASS", "NO_SIDE_STREAM", "NO_GRAM_MFMA", "NO_BIGK_FUSED"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -1122,7 +1122,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         hipLaunchKernelGGL(k_bigk_lipschitz, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga, 0);
         prof_stop(st); prof_start(1, st);
         launch_bigk_step(ga, nch, resid, st);
-        hipLaunchKernelGGL(k_bigk_sed, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga);
+        hipLaunchKernelGGL(k_bigk_sed, dim3(ga.S), dim3(SC_BLOCK), 0, st, ga, 0);
         prof_stop(st);
         HIP_TRY(hipGetLastError());
         return SCARLET_OK;
@@ -1275,6 +1275,32 @@ static int backward_impl(scarlet_batch *b, int approximate_L, int raw_gradient, 
         float *resid = ws_resid(b);
         SideStream *side = nullptr;
         if (!opt(OPT_NO_SIDE_STREAM) && (rc = side_stream(&side))) return rc;
+        if (!approximate_L && (a.HW & 63) == 0 && !opt(OPT_NO_BIGK_FUSED)) {
+            // residual + morphology step + SED-gradient sums in one pass on the matrix cores (k_bigk_fused); the Gram
+            // matrix and its eigenvalue beside it on the second stream:
+            //   stream : lmorph . fused ..... (join) sed (+ loss record)
+            //   side   : gram . lipschitz           (exact constants do not need the loss)
+            if (side) {
+                HIP_TRY(hipEventRecord(side->ev[0], st));
+                HIP_TRY(hipStreamWaitEvent(side->st, side->ev[0], 0));
+                launch_bigk_gram(a, nch, side->st);
+                hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_BLOCK), 0, side->st, a, 2);
+                HIP_TRY(hipEventRecord(side->ev[2], side->st));
+            }
+            prof_start(0, st);
+            hipLaunchKernelGGL(k_bigk_lmorph, dim3(a.S), dim3(SC_WAVE), 0, st, a);
+            prof_stop(st); prof_start(1, st);
+            hipLaunchKernelGGL(k_bigk_fused, grid, dim3(SC_BLOCK), 0, st, a);
+            if (side) HIP_TRY(hipStreamWaitEvent(st, side->ev[2], 0));
+            else {
+                launch_bigk_gram(a, nch, st);
+                hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_BLOCK), 0, st, a, 2);
+            }
+            hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a, 1);
+            prof_stop(st);
+            HIP_TRY(hipGetLastError());
+            return SCARLET_OK;
+        }
         if (side) {
             // The morphology step needs the residual planes and lambda_max(A^T A) only; the Gram matrix S S^T and
             // its largest eigenvalue (for the SED step) run beside it on a second stream:
@@ -1293,7 +1319,7 @@ static int backward_impl(scarlet_batch *b, int approximate_L, int raw_gradient, 
             prof_stop(st); prof_start(1, st);
             launch_bigk_step(a, nch, resid, st);
             HIP_TRY(hipStreamWaitEvent(st, side->ev[2], 0));
-            hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
+            hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a, 0);
             prof_stop(st);
             HIP_TRY(hipGetLastError());
             return SCARLET_OK;
@@ -1304,7 +1330,7 @@ static int backward_impl(scarlet_batch *b, int approximate_L, int raw_gradient, 
         hipLaunchKernelGGL(k_bigk_lipschitz, dim3(a.S), dim3(SC_BLOCK), 0, st, a, 0);
         prof_stop(st); prof_start(1, st);
         launch_bigk_step(a, nch, resid, st);
-        hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a);
+        hipLaunchKernelGGL(k_bigk_sed, dim3(a.S), dim3(SC_BLOCK), 0, st, a, 0);
         prof_stop(st);
         HIP_TRY(hipGetLastError());
         return SCARLET_OK;
