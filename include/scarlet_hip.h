@@ -77,8 +77,8 @@ extern "C" {
 const char *scarlet_version(void);
 const char *scarlet_last_error(void);
 /* Diagnostic switches: NO_EXACT, NO_KSCACHE, FUSED_V1, NO_FUSED, FORCE_BLOCK_UPDATE,
- * NO_HYBRID_SWEEP, PAD_LDS, STAMPS, PSF_HIPFFT, NO_PERSIST, NO_STAGGER, NO_BOX, NO_BOX2, NO_PSF3PASS, NO_SIDE_STREAM,
- * NO_GRAM_MFMA, NO_BIGK_FUSED.  Each starts from the environment variable
+ * NO_HYBRID_SWEEP, PAD_LDS, STAMPS, PSF_HIPFFT, NO_BOX, NO_BOX2, NO_PSF3PASS, NO_SIDE_STREAM,
+ * NO_GRAM_MFMA, NO_BIGK_FUSED, NO_PIPELINE.  Each starts from the environment variable
  * SCARLET_<NAME>, read once at first use; afterwards only this call changes it.  Returns the
  * previous value (0 / 1) or SCARLET_E_ARG for an unknown name.  None changes results beyond
  * float32 rounding. */

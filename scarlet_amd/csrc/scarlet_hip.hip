@@ -48,10 +48,10 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_PERSIST, OPT_NO_STAGGER, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_NO_GRAM_MFMA, OPT_NO_BIGK_FUSED, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_NO_GRAM_MFMA, OPT_NO_BIGK_FUSED, OPT_NO_PIPELINE, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
-                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_PERSIST", "NO_STAGGER", "NO_BOX", "NO_BOX2",
-                                                   "NO_PSF3PASS", "NO_SIDE_STREAM", "NO_GRAM_MFMA", "NO_BIGK_FUSED"};
+                                                   "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_BOX", "NO_BOX2",
+                                                   "NO_PSF3PASS", "NO_SIDE_STREAM", "NO_GRAM_MFMA", "NO_BIGK_FUSED", "NO_PIPELINE"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -685,7 +685,7 @@ extern "C" int scarlet_profile_begin(int max_iterations)
     if (max_iterations <= 0) return set_err(SCARLET_E_ARG, "max_iterations <= 0");
     std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto e : g_prof.ev) (void)hipEventDestroy(e);
-    const int cap = max_iterations * 4;
+    const int cap = max_iterations * 16;                 // (two half-batches per iteration when scarlet_fit pipelines them)
     g_prof.ev.assign((size_t)cap * 2, nullptr);
     g_prof.cls.assign(cap, 0);
     for (auto &e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
@@ -872,10 +872,58 @@ static PsfLayout psf_layout(const scarlet_batch *b)
     return l;
 }
 
+// ---- two half-batches on two streams (scarlet_fit with a PSF, LDS-resident transform, K <= 8).
+// The convolution kernel is bound by the latency of its passes at one workgroup per CU and moves under 1 TB/s;
+// the passes around it (model planes, gradient step, constraints) stream at HBM rate and hardly use the ALUs.
+// Scenes are independent, so scarlet_fit runs the two halves of a large batch as two pipelines, the second on the
+// calling thread's second stream: one half's convolution overlaps the other half's streaming passes.  Each half
+// is a VIEW of the batch (every per-scene array advanced to its first scene) with its own workspace region behind
+// the batch's (its own K-hat and tables, prepared with the batch's): the kernels do not know.
+static bool split_possible(const scarlet_batch *b)
+{
+    return b->diff_kernel && b->psf_h > 0 && b->psf_w > 0 && b->K <= SC_KMAX && b->S >= 1024 && !b->group &&
+           (b->H * b->W) % 4 == 0 && psf_lds_possible(b, nullptr);
+}
+static scarlet_batch batch_view(const scarlet_batch *b, int s0, int n, void *ws)
+{
+    scarlet_batch v = *b;
+    const size_t HW = (size_t)b->H * b->W, K = b->K, B = b->B;
+    v.S = n;
+    v.images += s0 * B * HW;
+    if (v.weights) v.weights += s0 * B * HW;
+    for (int i = 0; i < 2; ++i) { v.sed[i] += s0 * K * B; v.morph[i] += s0 * K * HW; }
+    v.cur += s0; v.centers += s0 * K * 2; v.shifts += s0 * K * 2; v.flags += s0 * K;
+    if (v.fix_sed) v.fix_sed += s0 * K;
+    if (v.fix_morph) v.fix_morph += s0 * K;
+    v.lipschitz += 2 * (size_t)s0; v.mse += (size_t)s0 * b->mse_capacity; v.it += s0; v.active += s0; v.status += s0;
+    if (v.diff_kernel_per_scene) v.diff_kernel += s0 * B * (size_t)b->psf_h * b->psf_w;
+    if (v.group) v.group += s0 * K;
+    v.workspace = ws;
+    return v;
+}
+static void split_views(const scarlet_batch *b, scarlet_batch v[2])
+{
+    const int n0 = ((b->S / 2 + 7) / 8) * 8;            // (the convolution maps groups of eight scenes to the XCDs)
+    char *ws = (char *)b->workspace + psf_layout(b).total;
+    v[0] = batch_view(b, 0, n0, ws);
+    v[1] = batch_view(b, n0, b->S - n0, ws + align256(psf_layout(&v[0]).total));
+}
+
 extern "C" int64_t scarlet_batch_workspace_bytes(const scarlet_batch *b)
 {
     if (!b) return 0;
-    if (b->diff_kernel && b->psf_h > 0 && b->psf_w > 0) return psf_layout(b).total;
+    if (b->diff_kernel && b->psf_h > 0 && b->psf_w > 0) {
+        int64_t total = psf_layout(b).total;
+        if (split_possible(b)) {
+            scarlet_batch v[2];
+            scarlet_batch tmp = *b;
+            tmp.workspace = nullptr;
+            const int n0 = ((b->S / 2 + 7) / 8) * 8;
+            v[0] = tmp; v[0].S = n0; v[1] = tmp; v[1].S = b->S - n0;
+            total += align256(psf_layout(&v[0]).total) + psf_layout(&v[1]).total;
+        }
+        return total;
+    }
     return base_workspace_bytes(b);
 }
 
@@ -958,7 +1006,18 @@ static int fft_c2r(const FftPlans &p, float2 *in, float *out, hipStream_t st)
 }
 static unsigned grid_for(int64_t n) { int64_t g = (n + SC_BLOCK - 1) / SC_BLOCK; return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
+static int prepare_psf_impl(scarlet_batch *b, void *stream);
 extern "C" int scarlet_batch_prepare_psf(scarlet_batch *b, void *stream)
+{
+    int rc = prepare_psf_impl(b, stream);
+    if (rc == SCARLET_OK && split_possible(b) && !opt(OPT_PSF_HIPFFT)) {
+        scarlet_batch v[2];
+        split_views(b, v);
+        for (int h = 0; h < 2 && rc == SCARLET_OK; ++h) rc = prepare_psf_impl(&v[h], stream);
+    }
+    return rc;
+}
+static int prepare_psf_impl(scarlet_batch *b, void *stream)
 {
     int rc = check_batch(b);
     if (rc) return rc;
@@ -1563,6 +1622,47 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
     int launched = 0;
     int *d_count = (int *)((char *)b->workspace + base_workspace_bytes(b) - 64);
     const bool fused = fused_ok(b, approximate_L);
+    if (!fused && split_possible(b) && !opt(OPT_PSF_HIPFFT) && !opt(OPT_NO_PIPELINE) && !opt(OPT_NO_SIDE_STREAM)) {
+        // two half-batches, two streams (see split_possible)
+        SideStream *side = nullptr;
+        if ((rc = side_stream(&side))) return rc;
+        if (side) {
+            scarlet_batch v[2];
+            split_views(b, v);
+            hipStream_t sv[2] = {st, side->st};
+            bool forked = false;
+            for (int i = 0; i < max_iter; ++i) {
+                if (!forked) {
+                    HIP_TRY(hipEventRecord(side->ev[0], st));
+                    HIP_TRY(hipStreamWaitEvent(side->st, side->ev[0], 0));
+                    forked = true;
+                }
+                for (int h = 0; h < 2; ++h) {
+                    if ((rc = scarlet_backward_step(&v[h], approximate_L, sv[h]))) return rc;
+                    prof_start(2, sv[h]);
+                    if ((rc = launch_update(&v[h], 1, 0, sv[h]))) return rc;
+                    prof_stop(sv[h]); prof_start(3, sv[h]);
+                    if ((rc = scarlet_check_convergence(&v[h], e_rel, sv[h]))) return rc;
+                    prof_stop(sv[h]);
+                }
+                ++launched;
+                const bool check = check_every > 0 && (i + 1) % check_every == 0 && i + 1 < max_iter;
+                if (check || i + 1 == max_iter) {
+                    HIP_TRY(hipEventRecord(side->ev[1], side->st));
+                    HIP_TRY(hipStreamWaitEvent(st, side->ev[1], 0));
+                    forked = false;
+                }
+                if (check) {
+                    int h_count = 0;
+                    hipLaunchKernelGGL(k_count_active, dim3(1), dim3(SC_BLOCK), 0, st, b->active, b->S, d_count);
+                    HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    if (h_count == 0) break;
+                }
+            }
+            return launched;
+        }
+    }
     for (int i = 0; i < max_iter; ++i) {
         if (fused) {
             if ((rc = launch_fused(b, e_rel, stream))) return rc;

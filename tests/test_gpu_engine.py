@@ -396,3 +396,42 @@ def test_config5_full_size_properties(BB):
     ms, ss, mses = run(ui, uc)
     idx = torch.arange(S, device=m.device) % U
     assert torch.equal(m, ms[idx]) and torch.equal(s, ss[idx]) and torch.equal(mse, mses[idx])
+
+
+@pytest.mark.parametrize("approx", [False, True])
+def test_many_component_forms_agree(BB, approx):
+    """K > 8: the forms of the gradient step behind the diagnostic switches -- one MFMA pass (k_bigk_fused) or
+    residual + chunked step; Gram matrix by MFMA or by chunk pairs; Gram + eigenvalue on the second stream or in
+    line -- are the same mathematics in different summation orders: equal iteration counts, values equal to
+    2e-6 of the array's maximum after 6 iterations (each form is also compared with the oracle by the tests above
+    with its switch at the default)."""
+    from scarlet_amd import synth, _lib
+    B, K, H, W, S = 6, 12, 64, 64, 3
+    scenes = [synth.make_scene(700 + i, B=B, H=H, W=W, K=K, min_sep=3) for i in range(S)]
+    rng = np.random.default_rng(5)
+    weights = rng.uniform(0.5, 1.5, size=(S, B, H, W)).astype(np.float32)
+    fix_morph = np.zeros((S, K), dtype=np.uint8); fix_morph[:, 2] = 1
+
+    def run(**opts):
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        try:
+            b = BB(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]), weights=weights)
+            b.init_extended(np.ones(B) * 0.1)
+            b.fix_morph = torch.as_tensor(fix_morph).cuda(); b._fill_struct()
+            b.fit(6, e_rel=1e-3, approximate_L=approx)
+            torch.cuda.synchronize()
+            assert int(b.status.abs().sum().item()) == 0
+            return (b.morph_current.cpu().numpy().copy(), b.sed_current.cpu().numpy().copy(),
+                    np.array([b.mse(i) for i in range(S)]), b.lipschitz.cpu().numpy().copy()), b.it.cpu().numpy().copy()
+        finally:
+            for k in opts:
+                _lib.set_option(k, 0)
+
+    ref, it_ref = run()
+    for opts in (dict(NO_BIGK_FUSED=1), dict(NO_BIGK_FUSED=1, NO_GRAM_MFMA=1), dict(NO_SIDE_STREAM=1),
+                 dict(NO_BIGK_FUSED=1, NO_SIDE_STREAM=1, NO_GRAM_MFMA=1)):
+        got, it = run(**opts)
+        np.testing.assert_array_equal(it, it_ref)
+        for x, y in zip(got, ref):
+            assert rel_err(x, y) < 2e-6, opts

@@ -377,3 +377,34 @@ def test_three_pass_iteration_equals_four_pass(scarlet, K, approx):
     assert_array_equal(out[0][4], out[1][4])
     for x, y in zip(out[0][:4], out[1][:4]):
         assert rel_err(x, y) < 2e-6
+
+
+def test_two_stream_pipeline_equals_single_stream(scarlet):
+    """scarlet_fit on a large PSF batch runs its two halves as two pipelines on two streams (views of the batch with
+    their own workspace regions and K-hat copies): scenes are independent, so every result must be bit-identical to
+    the single-stream run -- including ragged convergence (e_rel = 1e-2 with a host check every 3 iterations)."""
+    from scarlet_amd import synth, fft as fftmod, _lib
+    B, H, W, K, S = 3, 32, 32, 2, 1032
+    obs_psfs = np.array([synth.gaussian_psf((9, 9), 1.2 + 0.15 * b) for b in range(B)])
+    model_psf = synth.gaussian_psf((9, 9), 0.9)
+    diff = np.asarray(fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                        fftmod.Fourier(model_psf[None].astype(np.float32))).image, dtype=np.float32)
+    d = synth.make_batch(40, S, B=B, H=H, W=W, K=K, psfs=obs_psfs)
+    out = []
+    for off in (1, 0):
+        _lib.set_option("NO_PIPELINE", off)
+        try:
+            b = scarlet.BlendBatch(d["images"], d["centers"], centroid_weight=model_psf.astype(np.float32))
+            b.set_diff_kernel(diff)
+            b.init_extended(np.ones(B) * 0.1)
+            n = b.fit(12, e_rel=1e-2, check_every=3)
+            torch.cuda.synchronize()
+            assert int(b.status.abs().sum().item()) == 0
+            out.append((npy(b.morph_current), npy(b.sed_current), npy(b.it), npy(b.active), npy(b.lipschitz),
+                        npy(b.mse_buf), npy(b.centers), n))
+        finally:
+            _lib.set_option("NO_PIPELINE", 0)
+    assert out[0][-1] == out[1][-1]
+    for x, y in zip(out[0][:-1], out[1][:-1]):
+        assert_array_equal(x, y)
+    assert len(np.unique(out[0][2])) > 1          # the run was ragged
