@@ -45,16 +45,9 @@ for its in (3, 8):
           % (big.sum(), 100.0 * big.sum() / len(st), np.percentile(st[big, 8], [10, 50, 90, 100]) if big.any() else "-",
              (st[big, 7] - st[big, 0]).mean() if big.any() else 0))
     if big.any():
-        t0 = st[big, 0].min()
         dur = st[big, 7] - st[big, 0]
-        print("      127-box kernel timeline (cycles after the first start): starts 50/90/100 %%: %s, last end %d; per-component cycles 50/90/99/max: %s"
-              % (np.percentile(st[big, 0] - t0, [50, 90, 100]).astype(int), (st[big, 7] - t0).max(), np.percentile(dur, [50, 90, 99, 100]).astype(int)))
-        # (the cycle counters of the eight XCDs are not synchronised: timelines per XCD = workgroup index mod 8)
-        for x in range(8):
-            sel = big & (np.arange(len(st)) % 8 == x)
-            if sel.any():
-                span = (st[sel, 7].max() - st[sel, 0].min())
-                print("      XCD %d: %d components, makespan %d cycles, mean concurrency %.1f workgroups" % (x, sel.sum(), span, (st[sel, 7] - st[sel, 0]).sum() / span))
+        # (the cycle counters of the eight XCDs are not synchronised: only durations inside a workgroup mean anything)
+        print("      127-box per-component cycles 50/90/99/max: %s" % np.percentile(dur, [50, 90, 99, 100]).astype(int))
         for i, nm in enumerate(["max_pixel(+centroid)", "box load + vectors", "GEMM1 (X through LDS)", "rank-1 z", "GEMM2 + epilogue", "sweep", "final pass"]):
             print("      127-box %-24s %8.0f" % (nm, (st[big, i + 1] - st[big, i]).mean()))
     ok = ok & (st[:, 9] != 63)
