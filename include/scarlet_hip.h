@@ -260,6 +260,12 @@ typedef struct scarlet_batch {
 
 /* bytes of device workspace needed for `b` (depends on S, K, B, H, W only) */
 int64_t scarlet_batch_workspace_bytes(const scarlet_batch *b);
+/* Number of pipelines scarlet_fit() runs `b` as: 2 for a large batch with a PSF (>= 1024 scenes, K <= 8, the
+ * LDS-resident transform) -- the two halves of the batch as views with their own workspace regions, the second on the
+ * calling thread's second stream, joined back into the caller's stream before scarlet_fit() returns or synchronises,
+ * so that one half's convolution (latency-bound) runs beside the other half's streaming passes; results are
+ * bit-identical to one pipeline (scenes are independent).  1 otherwise, and with the NO_PIPELINE switch. */
+int scarlet_batch_pipelines(const scarlet_batch *b);
 
 /* Run up to `max_iter` proximal-gradient iterations on every active scene
  * (Blend.fit, blend.py:65-102).  Per iteration and scene: loss + analytic gradient

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "scarlet_resample": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
     "scarlet_apply_filter": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P]),
     "scarlet_batch_workspace_bytes": (c_int64, [POINTER(ScarletBatch)]),
+    "scarlet_batch_pipelines": (c_int, [POINTER(ScarletBatch)]),
     "scarlet_fit": (c_int, [POINTER(ScarletBatch), c_int, c_double, c_int, c_int, _P]),
     "scarlet_fit_multi": (c_int, [POINTER(ScarletBatch), POINTER(POINTER(ScarletBatch)), _P, c_int, c_int, c_double, c_int, c_int, _P]),
     "scarlet_backward_step": (c_int, [POINTER(ScarletBatch), c_int, _P]),

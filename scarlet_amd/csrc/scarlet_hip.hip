@@ -909,6 +909,12 @@ static void split_views(const scarlet_batch *b, scarlet_batch v[2])
     v[1] = batch_view(b, n0, b->S - n0, ws + align256(psf_layout(&v[0]).total));
 }
 
+extern "C" int scarlet_batch_pipelines(const scarlet_batch *b)
+{
+    if (!b) return 0;
+    return (split_possible(b) && !opt(OPT_PSF_HIPFFT) && !opt(OPT_NO_PIPELINE) && !opt(OPT_NO_SIDE_STREAM)) ? 2 : 1;
+}
+
 extern "C" int64_t scarlet_batch_workspace_bytes(const scarlet_batch *b)
 {
     if (!b) return 0;
@@ -1622,7 +1628,7 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
     int launched = 0;
     int *d_count = (int *)((char *)b->workspace + base_workspace_bytes(b) - 64);
     const bool fused = fused_ok(b, approximate_L);
-    if (!fused && split_possible(b) && !opt(OPT_PSF_HIPFFT) && !opt(OPT_NO_PIPELINE) && !opt(OPT_NO_SIDE_STREAM)) {
+    if (!fused && scarlet_batch_pipelines(b) == 2) {
         // two half-batches, two streams (see split_possible)
         SideStream *side = nullptr;
         if ((rc = side_stream(&side))) return rc;

@@ -82,6 +82,7 @@ def test_error_paths_return_codes_without_touching_memory():
     assert _lib.set_option("NO_FUSED", 1) == 0 and _lib.set_option("NO_FUSED", 0) == 1
     assert _lib.lib.scarlet_fit(None, 1, 0.0, 0, 0, None) == _lib.E_ARG
     assert _lib.lib.scarlet_batch_workspace_bytes(None) == 0
+    assert _lib.lib.scarlet_batch_pipelines(None) == 0
 
 
 def test_asan_error_paths():

@@ -17,7 +17,29 @@ bash tools/profile_round.sh ${TAG} > gpurun_out/${TAG}_profile_round.log 2>&1
 bash tools/profile_config.sh ${TAG} c3 10 > gpurun_out/${TAG}_prof_c3.log 2>&1
 bash tools/profile_config.sh ${TAG} c5 10 > gpurun_out/${TAG}_prof_c5.log 2>&1
 bash tools/pmc_any.sh ${TAG}_c3conv k_psf_conv tools/pmc_run_c3.py > gpurun_out/${TAG}_pmc_c3conv.log 2>&1
+python - ${TAG} <<'PY'
+# per-launch HBM traffic of k_psf_conv in the form bench.py looks up (scarlet_fit launches it per half-batch)
+import json, os, sys
+R = os.environ["GRAFT_REPO_ROOT"]; tag = sys.argv[1]
+pm = json.load(open(R + "/gpurun_out/pmc_%s_c3conv.json" % tag))
+S = 4096 // 2
+out = {"command": "bash tools/pmc_any.sh <tag> k_psf_conv tools/pmc_run_c3.py  (rocprofv3 --kernel-trace --pmc <set>, separate passes; "
+                  "4096 scenes, launched by scarlet_fit as two half-batches of 2048)",
+       "kernel": pm.get("kernel"), "scenes_per_launch": S, "launches": pm.get("launches"),
+       "note": "FETCH_SIZE / WRITE_SIZE in KiB per launch; FETCH_SIZE x 2 on gfx950 for wide coalesced reads (guide, HBM section); "
+               "the kernel's own stream is one 64 KiB model plane + one 64 KiB image plane read and one 64 KiB gradient plane "
+               "written per (scene, band)",
+       "FETCH_SIZE_mean_KiB": pm.get("FETCH_SIZE"), "WRITE_SIZE_mean_KiB": pm.get("WRITE_SIZE"),
+       "hbm_read_bytes_per_launch": pm.get("hbm_read_bytes_x2_correction"), "hbm_write_bytes_per_launch": pm.get("hbm_write_bytes"),
+       "hbm_bytes_per_launch": pm.get("hbm_read_bytes_x2_correction", 0) + pm.get("hbm_write_bytes", 0),
+       "kernel_own_bytes_per_launch (model + image read, G written)": S * 5 * 3 * 128 * 128 * 4,
+       "algorithmic_bytes_per_launch (whole iteration, SURVEY 8d)": S * (4 * 128 * 128 * (5 + 16) + 8 * 8 * 5),
+       "sq_counters_per_launch": {k: v for k, v in pm.items() if k.startswith("SQ_")}}
+json.dump(out, open(R + "/gpurun_out/%s_pmc_traffic_k_psf_conv.json" % tag, "w"), indent=1)
+PY
 python tools/stamps_c3.py > gpurun_out/${TAG}_stamps_k_psf_conv.txt 2>&1
-python tools/stamps_box.py c3 > gpurun_out/${TAG}_stamps_box_c3.txt 2>&1
+python tools/stamps_box.py c3psf > gpurun_out/${TAG}_stamps_box_c3.txt 2>&1
 python tools/stamps_box.py c5 > gpurun_out/${TAG}_stamps_box_c5.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1
+tail -1 gpurun_out/${TAG}_smoke.log
 tail -2 gpurun_out/${TAG}_gputest.log
