@@ -1427,6 +1427,8 @@ extern "C" int scarlet_backward_gradients(scarlet_batch *b, int approximate_L, v
     return backward_impl(b, approximate_L, 1, stream);
 }
 
+__global__ void k_zero_int(int *p) { *p = 0; }
+
 static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void *stream)
 {
     int rc = ensure_tables();
@@ -1461,7 +1463,7 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
         int *list = ws_box_list(b), *count = list + (size_t)b->S * b->K;
         hipStream_t st = (hipStream_t)stream;
         const bool second = !opt(OPT_NO_BOX2);
-        if (second) HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), st));
+        if (second) hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, st, count);   // (a 4-byte hipMemsetAsync costs 16 us)
         // the large box: workgroup i takes list[i]
         const int listed_grid = b->S * b->K;
         if (b->H <= 128 && b->W <= 128) {
