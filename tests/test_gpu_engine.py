@@ -435,3 +435,29 @@ def test_many_component_forms_agree(BB, approx):
         np.testing.assert_array_equal(it, it_ref)
         for x, y in zip(got, ref):
             assert rel_err(x, y) < 2e-6, opts
+
+
+def test_many_component_raw_gradients_forms_agree(BB):
+    """scarlet_backward_gradients (the raw d loss / d sed, d loss / d morph of one backward pass) with K > 8: the
+    one-pass MFMA kernel against the chunked passes, to 2e-6 of the arrays' maxima; loss and Lipschitz constants too."""
+    import ctypes
+    from scarlet_amd import synth, _lib
+    B, K, H, W, S = 6, 12, 64, 64, 2
+    scenes = [synth.make_scene(720 + i, B=B, H=H, W=W, K=K, min_sep=3) for i in range(S)]
+    out = []
+    for chunked in (0, 1):
+        _lib.set_option("NO_BIGK_FUSED", chunked)
+        try:
+            b = BB(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]))
+            b.init_extended(np.ones(B) * 0.1)
+            _lib.check(_lib.lib.scarlet_backward_gradients(ctypes.byref(b._c), 0, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            cur = b.cur.cpu().numpy()
+            g_sed = np.stack([b.sed[1 - cur[i]][i].cpu().numpy() for i in range(S)])
+            g_morph = np.stack([b.morph[1 - cur[i]][i].cpu().numpy() for i in range(S)])
+            out.append((g_sed, g_morph, b.lipschitz.cpu().numpy().copy(), b.mse_buf[:, 0].cpu().numpy().copy()))
+        finally:
+            _lib.set_option("NO_BIGK_FUSED", 0)
+    assert np.abs(out[0][1]).max() > 0
+    for x, y in zip(*out):
+        assert rel_err(x, y) < 2e-6
