@@ -255,6 +255,10 @@ __device__ inline double wave_lambda_max8(const double *A, int n, int ld, double
         buf[1 - cur][lane] = acc * (1.0 / t);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         cur ^= 1;
+        // tr(M^2) of the trace-normalised M is sum lambda_i^2 / (sum lambda_i)^2: 1 - t ~ 2 (lambda_2 / lambda_1)^(2^q).
+        // Once that is below float64 resolution M is u1 u1^T to round-off and further squarings change nothing
+        // (typically after 6 - 8 of the 30; with a (near-)degenerate top eigenvalue t never gets there and all 30 run)
+        if (1.0 - t < 1e-15) break;
     }
     int best = 0;
     double bv = buf[cur][0];
