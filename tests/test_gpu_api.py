@@ -681,3 +681,60 @@ def test_multicomponent_device_pipeline_on_a_large_frame(scarlet):
     assert rel_err(np.array([npy(c.morph) for c in bd.components]), np.array([npy(c.morph) for c in bp.components])) < 1e-5
     assert rel_err(np.array([npy(c.sed) for c in bd.components]), np.array([npy(c.sed) for c in bp.components])) < 1e-5
     assert tuple(md.pixel_center) == tuple(mp.pixel_center)
+
+
+@pytest.mark.parametrize("case", ["many components (second stream beside the gradient pass)",
+                                  "PSF batch of 1032 scenes (two half-batch pipelines)"])
+def test_iteration_with_second_stream_survives_graph_capture(scarlet, case):
+    """The library forks work onto a per-thread second stream and joins it back by events (include/scarlet_hip.h):
+    a caller that captures its stream into a graph must get both branches.  One scarlet_fit iteration captured,
+    replayed four times after one eager warm-up iteration, against five eager iterations: bit-identical."""
+    import ctypes
+    from scarlet_amd import synth, _lib, fft as fftmod
+    if case.startswith("many"):
+        B, K, H, W, S = 6, 12, 64, 64, 4
+        scenes = [synth.make_scene(700 + i, B=B, H=H, W=W, K=K, min_sep=3) for i in range(S)]
+        images, centers = np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes])
+        kw, diff = {}, None
+    else:
+        B, K, H, W, S = 3, 2, 32, 32, 1032
+        obs_psfs = np.array([synth.gaussian_psf((9, 9), 1.2 + 0.15 * b) for b in range(B)])
+        model_psf = synth.gaussian_psf((9, 9), 0.9)
+        diff = np.asarray(fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                            fftmod.Fourier(model_psf[None].astype(np.float32))).image, dtype=np.float32)
+        d = synth.make_batch(40, S, B=B, H=H, W=W, K=K, psfs=obs_psfs)
+        images, centers, kw = d["images"], d["centers"], dict(centroid_weight=model_psf.astype(np.float32))
+
+    def make():
+        b = scarlet.BlendBatch(images, centers, **kw)
+        if diff is not None:
+            b.set_diff_kernel(diff)
+        b.init_extended(np.ones(B) * 0.1)
+        return b
+
+    ref = make()
+    ref.fit(5, e_rel=0, check_every=0)
+    torch.cuda.synchronize()
+    b = make()
+    b._ensure_mse_capacity(16)
+    if diff is not None:
+        assert _lib.lib.scarlet_batch_pipelines(ctypes.byref(b._c)) == 2
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sp = ctypes.c_void_p(st.cuda_stream)
+
+        def one_iteration():
+            assert _lib.lib.scarlet_fit(ctypes.byref(b._c), 1, 0.0, 0, 0, sp) == 1
+        one_iteration()                      # eager: creates the second stream, sets the kernel attributes
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            one_iteration()
+        torch.cuda.synchronize()
+        for _ in range(4):
+            g.replay()
+        torch.cuda.synchronize()
+    np.testing.assert_array_equal(npy(b.it), npy(ref.it))
+    np.testing.assert_array_equal(npy(b.morph_current), npy(ref.morph_current))
+    np.testing.assert_array_equal(npy(b.sed_current), npy(ref.sed_current))
+    np.testing.assert_array_equal(npy(b.mse_buf)[:, :5], npy(ref.mse_buf)[:, :5])
