@@ -344,7 +344,9 @@ def main():
     elif dom == 5:
         kernel_label = "k_psf_conv (render + adjoint, LDS-resident FFT)" if not os.environ.get("SCARLET_PSF_HIPFFT") else "psf_chain (hipFFT)"
     elif dom == 2:
-        kernel_label = "k_source_update"
+        # frames beyond 64 x 64: the constraint pipeline on the box around each peak (boxupdate.h)
+        kernel_label = "k_source_update_box (constraints on the 63 x 63 box; class time includes the listed 127 x 127 pass)" \
+            if (H > 64 or W > 64) and not os.environ.get("SCARLET_NO_BOX") else "k_source_update"
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes" if args.traffic_bytes else None
     if traffic is None:
         import glob

@@ -37,6 +37,26 @@ out = {"command": "bash tools/pmc_any.sh <tag> k_psf_conv tools/pmc_run_c3.py  (
        "sq_counters_per_launch": {k: v for k, v in pm.items() if k.startswith("SQ_")}}
 json.dump(out, open(R + "/gpurun_out/%s_pmc_traffic_k_psf_conv.json" % tag, "w"), indent=1)
 PY
+bash tools/pmc_any.sh ${TAG}_c5box "k_source_update_box<16>" tools/pmc_run_c5.py > gpurun_out/${TAG}_pmc_c5box.log 2>&1
+python - ${TAG} <<'PY'
+# per-launch HBM traffic of config 5's dominant kernel (the 63 x 63 box on 256 x 256 planes), in the form bench.py looks up
+import json, os, sys
+R = os.environ["GRAFT_REPO_ROOT"]; tag = sys.argv[1]
+pm = json.load(open(R + "/gpurun_out/pmc_%s_c5box.json" % tag))
+S, K, HW = 64, 30, 256 * 256
+out = {"command": "bash tools/pmc_any.sh <tag> 'k_source_update_box<16>' tools/pmc_run_c5.py  (rocprofv3 --kernel-trace --pmc <set>, separate passes; 64 scenes)",
+       "kernel": pm.get("kernel"), "scenes_per_launch": S, "launches": pm.get("launches"),
+       "note": "FETCH_SIZE / WRITE_SIZE in KiB per launch; FETCH_SIZE x 2 on gfx950 for wide coalesced reads (guide, HBM section).  "
+               "The kernel's own streams per component: the stepped plane (window rows, GEMM 1) and the previous plane (convergence "
+               "sums) read, the new plane written: 3 x 256 KiB",
+       "FETCH_SIZE_mean_KiB": pm.get("FETCH_SIZE"), "WRITE_SIZE_mean_KiB": pm.get("WRITE_SIZE"),
+       "hbm_read_bytes_per_launch": pm.get("hbm_read_bytes_x2_correction"), "hbm_write_bytes_per_launch": pm.get("hbm_write_bytes"),
+       "hbm_bytes_per_launch": pm.get("hbm_read_bytes_x2_correction", 0) + pm.get("hbm_write_bytes", 0),
+       "kernel_own_bytes_per_launch (two planes read, one written per component)": S * K * 3 * HW * 4,
+       "algorithmic_bytes_per_launch (whole iteration, SURVEY 8d)": S * (4 * HW * (6 + 2 * K) + 8 * K * 6),
+       "sq_counters_per_launch": {k: v for k, v in pm.items() if k.startswith("SQ_")}}
+json.dump(out, open(R + "/gpurun_out/%s_pmc_traffic_k_source_update_box_c5.json" % tag, "w"), indent=1)
+PY
 python tools/stamps_c3.py > gpurun_out/${TAG}_stamps_k_psf_conv.txt 2>&1
 python tools/stamps_box.py c3psf > gpurun_out/${TAG}_stamps_box_c3.txt 2>&1
 python tools/stamps_box.py c5 > gpurun_out/${TAG}_stamps_box_c5.txt 2>&1

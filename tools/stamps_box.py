@@ -1,6 +1,7 @@
 """Phase stamps of k_source_update_box (SCARLET_STAMPS=1) on config 3's or config 5's shape: cycles per phase."""
 import sys, os, ctypes
 os.environ["SCARLET_STAMPS"] = "1"
+os.environ["SCARLET_NO_PIPELINE"] = "1"      # (the stamp buffer is indexed by the batch's own scene numbers: one pipeline)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from scarlet_amd import synth, _lib

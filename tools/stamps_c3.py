@@ -1,6 +1,7 @@
 """Phase stamps of k_psf_conv (SCARLET_STAMPS=1): shader-clock cycles per pass, mean over planes."""
 import sys, os
 os.environ["SCARLET_STAMPS"] = "1"
+os.environ["SCARLET_NO_PIPELINE"] = "1"      # (the stamp buffer is indexed by the batch's own scene numbers: one pipeline)
 os.environ.setdefault("PMC_SCENES", "4096"); os.environ["PMC_ITERS"] = "3"
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import runpy, numpy as np, torch
