@@ -461,3 +461,52 @@ def test_many_component_raw_gradients_forms_agree(BB):
     assert np.abs(out[0][1]).max() > 0
     for x, y in zip(*out):
         assert rel_err(x, y) < 2e-6
+
+
+@pytest.mark.parametrize("B,K,H,W,P,path", [
+    (5, 4, 64, 64, None, "k_grad / k_step"),
+    (6, 12, 64, 64, None, "k_bigk_fused + k_bigk_gram_mfma"),
+    (3, 3, 32, 40, (9, 9), "k_psf_conv (LDS-resident FFT) + three-pass form"),
+])
+def test_device_gradients_equal_autograd(BB, B, K, H, W, P, path):
+    """Row a5 on the device against automatic differentiation (no oracle in between): scarlet_backward_gradients'
+    d loss / d sed and d loss / d morph (float32) against torch.autograd over the float64 forward chain of
+    tests/test_oracle_autograd.py, 1e-5 of the arrays' maxima; the loss too."""
+    import ctypes
+    from scarlet_amd import synth, _lib, fft as fftmod
+    from test_oracle_autograd import _render_torch
+    S = 2
+    kw = {}
+    diff = None
+    if P is not None:
+        obs_psfs = np.array([synth.gaussian_psf(P, 1.2 + 0.15 * b) for b in range(B)])
+        model_psf = synth.gaussian_psf(P, 0.9)
+        diff = np.asarray(fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                            fftmod.Fourier(model_psf[None].astype(np.float32))).image, dtype=np.float32)
+        scenes = [synth.make_scene(810 + i, B=B, H=H, W=W, K=K, psfs=obs_psfs) for i in range(S)]
+        kw = dict(centroid_weight=model_psf.astype(np.float32))
+    else:
+        scenes = [synth.make_scene(810 + i, B=B, H=H, W=W, K=K, min_sep=3) for i in range(S)]
+    rng = np.random.default_rng(3)
+    weights = rng.uniform(0.5, 1.5, size=(S, B, H, W)).astype(np.float32)
+    b = BB(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]), weights=weights, **kw)
+    if diff is not None:
+        b.set_diff_kernel(diff)
+    b.init_extended(np.ones(B) * 0.1)
+    sed0, morph0 = b.sed_current.cpu().numpy().astype(np.float64), b.morph_current.cpu().numpy().astype(np.float64)
+    _lib.check(_lib.lib.scarlet_backward_gradients(ctypes.byref(b._c), 0, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    cur = b.cur.cpu().numpy()
+    for i in range(S):
+        g_sed = b.sed[1 - cur[i]][i].cpu().numpy()
+        g_morph = b.morph[1 - cur[i]][i].cpu().numpy()
+        ts = torch.tensor(sed0[i], requires_grad=True)
+        tm = torch.tensor(morph0[i], requires_grad=True)
+        model = torch.einsum("kb,kyx->byx", ts, tm)
+        rendered = _render_torch(model, None if diff is None else torch.tensor(diff.astype(np.float64)))
+        d = torch.tensor(weights[i].astype(np.float64)) * (rendered - torch.tensor(scenes[i]["images"].astype(np.float64)))
+        tl = 0.5 * (d ** 2).sum()
+        ag_sed, ag_morph = torch.autograd.grad(tl, (ts, tm))
+        assert rel_err(g_sed, ag_sed.numpy()) < TOL, path
+        assert rel_err(g_morph, ag_morph.numpy()) < TOL, path
+        assert abs(float(b.mse_buf[i, 0].item()) - float(tl)) < TOL * abs(float(tl)), path
