@@ -375,8 +375,16 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
     if (vec4) {
         const int gpr = W >> 2, ngroups = HW >> 2;
         const bool plain = regular && l0 < 0.f && l1 < 0.f;       // no thresholds, finite positive norm: the common case
-        auto do_group = [&](int g, const float4 &l) {
-            const int y = g / gpr, x = (g - y * gpr) << 2;
+        // Row and column of a thread's groups without a division per group: when the groups of a row divide the
+        // workgroup (W = 16 .. 1024 in powers of two), group threadIdx.x + j * 256 sits in the thread's own column,
+        // 256 / gpr rows further down per j (the division was ~20 of the ~70 instructions of a group, and the pass
+        // costs its instruction count: 64 groups per thread on a 256 x 256 plane)
+        const bool rowstep = (SC_BLOCK % gpr) == 0;
+        const int ty = threadIdx.x / gpr, tx = (threadIdx.x - ty * gpr) << 2, dyj = rowstep ? SC_BLOCK / gpr : 0;
+        auto do_group = [&](int g, int jj, const float4 &l) {
+            int y, x;
+            if (rowstep) { y = ty + jj * dyj; x = tx; }
+            else { y = g / gpr; x = (g - y * gpr) << 2; }
             float o[4];
             // level(x, y) = 2 max(ax, ay) + min(ax, ay) <= lstop  <=>  ax <= axmax(ay): one bound per group's row
             // instead of a level per pixel (as the fused kernel's final pass does); lstop <= 2 R keeps it inside the box
@@ -409,7 +417,7 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
 #pragma unroll
         for (int j = 0; j < NLAST; ++j) {
             const int g = threadIdx.x + j * SC_BLOCK;
-            if (g < ngroups) do_group(g, lastv[j]);
+            if (g < ngroups) do_group(g, j, lastv[j]);
         }
         // larger frames: the remaining groups in chunks of NLAST, loads of a chunk together before its stores
         for (int g0 = NLAST * SC_BLOCK; g0 < ngroups; g0 += NLAST * SC_BLOCK) {
@@ -421,7 +429,7 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
 #pragma unroll
             for (int j = 0; j < NLAST; ++j) {
                 const int g = g0 + threadIdx.x + j * SC_BLOCK;
-                if (g < ngroups) do_group(g, lastv[j]);
+                if (g < ngroups) do_group(g, g0 / SC_BLOCK + j, lastv[j]);
             }
         }
     } else {
