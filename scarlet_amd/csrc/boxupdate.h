@@ -129,18 +129,23 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
     Tile bt; bt.H = bh; bt.W = bw; bt.LW = SC_UB_LW; bt.m = box;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
     const int hW = sw.h, wW = sw.w, wpW = round16(wW);
-    // band of BR window rows x wp columns: element e = threadIdx.x + j * 256 -> (row e / wp, column e % wp)
+    // band of BR window rows x wp columns: value j of a thread is row j (NB = 16: the 256 threads span the columns) or
+    // row 2 j + threadIdx.x / 128 (NB = 8: two rows of up to 128 columns per j) -- no index division, a row's lanes
+    // read consecutive addresses (the first form, element e = threadIdx.x + j * 256 -> (e / wp, e % wp), spent ~20
+    // instructions per value on the division, twice: load and LDS store).
     // values per thread and band: the NB = 8 instance serves frames up to 128 x 128 (wp <= 128: 8 values) and keeps
     // TWO bands in flight -- with one, each band of the first product waited a full HBM round trip (~6 k cycles x 8
     // bands, measured) --, the NB = 16 instance (wp <= 256: 16 values) one
     constexpr int NBAND = NB == 8 ? 8 : 16, NPF = NB == 8 ? 2 : 1;
     float xr[NPF][NBAND];
+    constexpr int BCOLS = NB == 8 ? 128 : 256, BRPJ = SC_BLOCK / BCOLS;            // columns and rows covered per value index
+    static_assert(NBAND * BRPJ == SC_UB_BR, "a band is NBAND values per thread");
+    const int bcc = threadIdx.x & (BCOLS - 1), brr = threadIdx.x / BCOLS;
     auto load_band = [&](int i0, int slot) {
 #pragma unroll
         for (int j = 0; j < NBAND; ++j) {
-            const int e = threadIdx.x + j * SC_BLOCK;
-            const int r = e / wpW, cc = e - r * wpW;
-            const float v = (e < SC_UB_BR * wpW && i0 + r < hW && cc < wW) ? gm[(sw.y0 + i0 + r) * W + sw.x0 + cc] : 0.f;
+            const int r = j * BRPJ + brr, cc = bcc;
+            const float v = (i0 + r < hW && cc < wW) ? gm[(sw.y0 + i0 + r) * W + sw.x0 + cc] : 0.f;
 #pragma unroll
             for (int q = 0; q < NPF; ++q) if (q == slot) xr[q][j] = v;
         }
@@ -187,9 +192,8 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
                 __syncthreads();                                   // vectors ready / previous band consumed
 #pragma unroll
                 for (int j = 0; j < NBAND; ++j) {
-                    const int e = threadIdx.x + j * SC_BLOCK;
-                    const int r = e / wp, cc = e - r * wp;
-                    if (e < BR * wp) stage[r * SW + cc] = xr[bi % NPF][j];
+                    const int r = j * BRPJ + brr;
+                    if (bcc < wp) stage[r * SW + bcc] = xr[bi % NPF][j];
                 }
                 __syncthreads();
                 if (i0 + NPF * BR < hp) load_band(i0 + NPF * BR, bi % NPF);     // NPF bands ahead: in flight under the MFMAs
