@@ -116,14 +116,16 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
     // 16 values per thread) and the first band of window rows now, under the float64 trigonometry of the vectors
     // (the large box is read when it is stored instead: 64 registers per thread are not free)
     constexpr bool BOX_REGS = R <= 31;
-    constexpr int NBX = BOX_REGS ? ((2 * R + 1) * (2 * R + 1) + SC_BLOCK - 1) / SC_BLOCK : 1;      // 63 * 63 / 256 -> 16
+    // box pixel of a thread's value j: column threadIdx.x % BXC, row j * BXR + threadIdx.x / BXC (no index division)
+    constexpr int BXC = R <= 31 ? 64 : 128, BXR = SC_BLOCK / BXC, NBXJ = (2 * R + 1 + BXR - 1) / BXR;    // 64 x 4 x 16, 128 x 2 x 64
+    constexpr int NBX = BOX_REGS ? NBXJ : 1;
+    const int bxx = threadIdx.x & (BXC - 1), bxy = threadIdx.x / BXC;
     float bxr[NBX];
     if (BOX_REGS) {
 #pragma unroll
         for (int j = 0; j < NBX; ++j) {
-            const int i = threadIdx.x + j * SC_BLOCK;
-            const int y = i / bw, x = i - y * bw;
-            bxr[j] = i < bh * bw ? gm[(by0 + y) * W + bx0 + x] : 0.f;
+            const int y = j * BXR + bxy;
+            bxr[j] = (y < bh && bxx < bw) ? gm[(by0 + y) * W + bx0 + bxx] : 0.f;
         }
     }
     Tile bt; bt.H = bh; bt.W = bw; bt.LW = SC_UB_LW; bt.m = box;
@@ -158,14 +160,14 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
         if (BOX_REGS) {
 #pragma unroll
             for (int j = 0; j < NBX; ++j) {
-                const int i = threadIdx.x + j * SC_BLOCK;
-                const int y = i / bw, x = i - y * bw;
-                if (i < bh * bw) box[y * SC_UB_LW + x] = bxr[j];
+                const int y = j * BXR + bxy;
+                if (y < bh && bxx < bw) box[y * SC_UB_LW + bxx] = bxr[j];
             }
         } else {
-            for (int i = threadIdx.x; i < bh * bw; i += SC_BLOCK) {
-                const int y = i / bw, x = i - y * bw;
-                box[y * SC_UB_LW + x] = gm[(by0 + y) * W + bx0 + x];
+#pragma unroll 8
+            for (int j = 0; j < NBXJ; ++j) {
+                const int y = j * BXR + bxy;
+                if (y < bh && bxx < bw) box[y * SC_UB_LW + bxx] = gm[(by0 + y) * W + bx0 + bxx];
             }
         }
     };
