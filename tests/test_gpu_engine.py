@@ -510,3 +510,35 @@ def test_device_gradients_equal_autograd(BB, B, K, H, W, P, path):
         assert rel_err(g_sed, ag_sed.numpy()) < TOL, path
         assert rel_err(g_morph, ag_morph.numpy()) < TOL, path
         assert abs(float(b.mse_buf[i, 0].item()) - float(tl)) < TOL * abs(float(tl)), path
+
+
+@pytest.mark.parametrize("B,K,H,W,l0,mode", [
+    (3, 3, 96, 80, -1.0, "tile in LDS (k_source_update<0/1>)"),
+    (5, 8, 128, 128, -1.0, "tile in LDS, scratch in HBM (k_source_update<1>)"),
+    (6, 10, 256, 256, 0.05, "plane in HBM (k_source_update<2>), L0"),
+])
+def test_full_frame_constraint_kernels_agree_with_the_box_kernels(BB, B, K, H, W, l0, mode):
+    """Frames beyond 64 x 64 run their constraints on the box around each peak (boxupdate.h); the full-frame kernels of
+    round 1 remain as the last resort for footprints beyond 127 x 127 and are rarely reached.  Forced here for every
+    component (NO_BOX) and compared with the box path: same centres and iteration counts, values to 5e-6 of the
+    arrays' maxima (the symmetry sums run in a different order)."""
+    from scarlet_amd import synth, _lib
+    S = 2
+    scenes = [synth.make_scene(640 + i, B=B, H=H, W=W, K=K, min_sep=3) for i in range(S)]
+    out = []
+    for full in (0, 1):
+        _lib.set_option("NO_BOX", full)
+        try:
+            b = BB(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]), l0_thresh=l0)
+            b.init_extended(np.ones(B) * 0.1)
+            b.fit(6, e_rel=1e-3)
+            torch.cuda.synchronize()
+            assert int(b.status.abs().sum().item()) == 0
+            out.append((b.morph_current.cpu().numpy().copy(), b.sed_current.cpu().numpy().copy(),
+                        np.array([b.mse(i) for i in range(S)]), b.centers.cpu().numpy().copy(), b.it.cpu().numpy().copy()))
+        finally:
+            _lib.set_option("NO_BOX", 0)
+    np.testing.assert_array_equal(out[0][3], out[1][3])
+    np.testing.assert_array_equal(out[0][4], out[1][4])
+    for x, y in zip(out[0][:3], out[1][:3]):
+        assert rel_err(x, y) < 5e-6, mode
