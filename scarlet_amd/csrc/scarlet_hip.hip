@@ -1639,6 +1639,12 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
             split_views(b, v);
             hipStream_t sv[2] = {st, side->st};
             bool forked = false;
+            // (an error between fork and join: the caller's stream still gets the second stream's work ordered before
+            // anything it enqueues next)
+            auto bail = [&](int code) {
+                if (forked && hipEventRecord(side->ev[1], side->st) == hipSuccess) (void)hipStreamWaitEvent(st, side->ev[1], 0);
+                return code;
+            };
             for (int i = 0; i < max_iter; ++i) {
                 if (!forked) {
                     HIP_TRY(hipEventRecord(side->ev[0], st));
@@ -1646,11 +1652,11 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
                     forked = true;
                 }
                 for (int h = 0; h < 2; ++h) {
-                    if ((rc = scarlet_backward_step(&v[h], approximate_L, sv[h]))) return rc;
+                    if ((rc = scarlet_backward_step(&v[h], approximate_L, sv[h]))) return bail(rc);
                     prof_start(2, sv[h]);
-                    if ((rc = launch_update(&v[h], 1, 0, sv[h]))) return rc;
+                    if ((rc = launch_update(&v[h], 1, 0, sv[h]))) return bail(rc);
                     prof_stop(sv[h]); prof_start(3, sv[h]);
-                    if ((rc = scarlet_check_convergence(&v[h], e_rel, sv[h]))) return rc;
+                    if ((rc = scarlet_check_convergence(&v[h], e_rel, sv[h]))) return bail(rc);
                     prof_stop(sv[h]);
                 }
                 ++launched;
