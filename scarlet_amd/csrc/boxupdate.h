@@ -48,7 +48,9 @@ __host__ __device__ inline size_t ub_lds_floats(int H, int W, int R)
 // ub_component: the pipeline for component `c` by the calling workgroup (every return is uniform over it).
 // `list` / `count` != NULL (the small box): a component whose sweep leaves the box is appended to the list for the
 // large-box kernel; without them it is only flagged in `fallback` (the full-frame kernel runs for those).
-template <int NB, int R>
+// XS: 0 = frame shape from the arguments; 128 / 256 = a square frame of that size as compile-time constants (BASELINE
+// configs 3 and 5: the address arithmetic folds, as in the headline kernel's exact-shape instance)
+template <int NB, int R, int XS>
 __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, int *fallback, int *list, int *count, long long *stamps_all)
 {
     constexpr int SC_UB_R = R, SC_UB_LW = ub_lw(R), SC_UB_FLOATS = ub_floats(R), SC_UB_N = ub_n(R), SC_UB_NT = SC_UB_N / 16;
@@ -59,7 +61,7 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
     long long *stamps = stamps_all ? stamps_all + (size_t)c * 16 : nullptr;
 #define UB_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     UB_STAMP(0);
-    const int H = a.H, W = a.W, HW = H * W, B = a.B;
+    const int H = XS ? XS : a.H, W = XS ? XS : a.W, HW = H * W, B = a.B;
     const int hpF = round16(H), wpF = round16(W);
     const int BR = SC_UB_BR, SW = tile_stride(wpF);
     float *stage = lds;                                   // [BR][SW]   band of X rows (GEMM 1) ...
@@ -476,10 +478,10 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
 
 // NB: bands of 16 window rows the kernel is built for (8: frames up to 128 rows, 16: up to 256).
 // The small box: one workgroup per component, four per CU.
-template <int NB>
+template <int NB, int XS>
 __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a, int *fallback, int *list, int *count, long long *stamps_all)
 {
-    ub_component<NB, 31>(a, blockIdx.x, fallback, list, count, stamps_all);
+    ub_component<NB, 31, XS>(a, blockIdx.x, fallback, list, count, stamps_all);
 }
 
 // The large box for the listed components: workgroup i takes list[i]; workgroups past the end of the list exit at
@@ -487,10 +489,10 @@ __global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a,
 // component of the batch with an early exit for the unlisted ones BETWEEN the listed ones, kept ~0.6 of the two
 // resident workgroups per CU busy: 0.7 ms for the ~4 % listed components of BASELINE config 3.  A loop over the
 // list inside the workgroup costs the register budget: the body's per-thread invariants get hoisted and spill.)
-template <int NB>
+template <int NB, int XS>
 __global__ __launch_bounds__(SC_BLOCK, 2) void k_source_update_box_listed(UpdateArgs a, int *fallback, const int *list, const int *count,
                                                                            long long *stamps_all)
 {
     if ((int)blockIdx.x >= *count) return;
-    ub_component<NB, 63>(a, list[blockIdx.x], fallback, nullptr, nullptr, stamps_all);
+    ub_component<NB, 63, XS>(a, list[blockIdx.x], fallback, nullptr, nullptr, stamps_all);
 }

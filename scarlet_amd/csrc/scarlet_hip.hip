@@ -1466,17 +1466,22 @@ static int launch_update(scarlet_batch *b, int in_iteration, int force_it0, void
         if (second) hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, st, count);   // (a 4-byte hipMemsetAsync costs 16 us)
         // the large box: workgroup i takes list[i]
         const int listed_grid = b->S * b->K;
-        if (b->H <= 128 && b->W <= 128) {
-            if ((rc = allow_lds(k_source_update_box<8>, lds1)) || (rc = allow_lds(k_source_update_box_listed<8>, lds2))) return rc;
-            hipLaunchKernelGGL((k_source_update_box<8>), dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, fb, second ? list : nullptr, count, dbg);
+        // instances: bands of X per frame height (8: up to 128 rows, 16: up to 256), and the two BASELINE frame shapes
+        // (128 x 128, 256 x 256) as compile-time constants
+        auto run = [&](auto small_k, auto listed_k) -> int {
+            int r2;
+            if ((r2 = allow_lds(small_k, lds1)) || (r2 = allow_lds(listed_k, lds2))) return r2;
+            hipLaunchKernelGGL(small_k, dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, fb, second ? list : nullptr, count, dbg);
             if (second)
-                hipLaunchKernelGGL((k_source_update_box_listed<8>), dim3(listed_grid), dim3(SC_BLOCK), lds2, st, u, fb, (const int *)list, (const int *)count, dbg);
-        } else {
-            if ((rc = allow_lds(k_source_update_box<16>, lds1)) || (rc = allow_lds(k_source_update_box_listed<16>, lds2))) return rc;
-            hipLaunchKernelGGL((k_source_update_box<16>), dim3(b->S * b->K), dim3(SC_BLOCK), lds1, st, u, fb, second ? list : nullptr, count, dbg);
-            if (second)
-                hipLaunchKernelGGL((k_source_update_box_listed<16>), dim3(listed_grid), dim3(SC_BLOCK), lds2, st, u, fb, (const int *)list, (const int *)count, dbg);
-        }
+                hipLaunchKernelGGL(listed_k, dim3(listed_grid), dim3(SC_BLOCK), lds2, st, u, fb, (const int *)list, (const int *)count, dbg);
+            return SCARLET_OK;
+        };
+        const bool exact = !opt(OPT_NO_EXACT);
+        if (exact && b->H == 128 && b->W == 128) rc = run(k_source_update_box<8, 128>, k_source_update_box_listed<8, 128>);
+        else if (exact && b->H == 256 && b->W == 256) rc = run(k_source_update_box<16, 256>, k_source_update_box_listed<16, 256>);
+        else if (b->H <= 128 && b->W <= 128) rc = run(k_source_update_box<8, 0>, k_source_update_box_listed<8, 0>);
+        else rc = run(k_source_update_box<16, 0>, k_source_update_box_listed<16, 0>);
+        if (rc) return rc;
         u.only_flagged = fb;
     }
     if (b->H <= 64 && b->W <= 64 && !opt(OPT_FORCE_BLOCK_UPDATE)) {

@@ -542,3 +542,27 @@ def test_full_frame_constraint_kernels_agree_with_the_box_kernels(BB, B, K, H, W
     np.testing.assert_array_equal(out[0][4], out[1][4])
     for x, y in zip(out[0][:3], out[1][:3]):
         assert rel_err(x, y) < 5e-6, mode
+
+
+@pytest.mark.parametrize("B,K,N,l0", [(5, 8, 128, -1.0), (6, 10, 256, 0.05)])
+def test_exact_shape_box_instances_are_bit_identical_to_the_generic_ones(BB, B, K, N, l0):
+    """The box kernels have instances with the BASELINE frame shapes (128 x 128, 256 x 256) as compile-time constants
+    (boxupdate.h, XS): the same arithmetic with the address computations folded -- bit-identical to the generic
+    instances (NO_EXACT)."""
+    from scarlet_amd import synth, _lib
+    S = 2
+    scenes = [synth.make_scene(660 + i, B=B, H=N, W=N, K=K, min_sep=3) for i in range(S)]
+    out = []
+    for generic in (0, 1):
+        _lib.set_option("NO_EXACT", generic)
+        try:
+            b = BB(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]), l0_thresh=l0)
+            b.init_extended(np.ones(B) * 0.1)
+            b.fit(6, e_rel=1e-3)
+            torch.cuda.synchronize()
+            out.append((b.morph_current.cpu().numpy().copy(), b.sed_current.cpu().numpy().copy(), b.mse_buf.cpu().numpy().copy(),
+                        b.centers.cpu().numpy().copy(), b.it.cpu().numpy().copy(), b.shifts.cpu().numpy().copy()))
+        finally:
+            _lib.set_option("NO_EXACT", 0)
+    for x, y in zip(*out):
+        np.testing.assert_array_equal(x, y)
