@@ -37,14 +37,14 @@ out = {"command": "bash tools/pmc_any.sh <tag> k_psf_conv tools/pmc_run_c3.py  (
        "sq_counters_per_launch": {k: v for k, v in pm.items() if k.startswith("SQ_")}}
 json.dump(out, open(R + "/gpurun_out/%s_pmc_traffic_k_psf_conv.json" % tag, "w"), indent=1)
 PY
-bash tools/pmc_any.sh ${TAG}_c5box "k_source_update_box<16>" tools/pmc_run_c5.py > gpurun_out/${TAG}_pmc_c5box.log 2>&1
+bash tools/pmc_any.sh ${TAG}_c5box "k_source_update_box<16" tools/pmc_run_c5.py > gpurun_out/${TAG}_pmc_c5box.log 2>&1
 python - ${TAG} <<'PY'
 # per-launch HBM traffic of config 5's dominant kernel (the 63 x 63 box on 256 x 256 planes), in the form bench.py looks up
 import json, os, sys
 R = os.environ["GRAFT_REPO_ROOT"]; tag = sys.argv[1]
 pm = json.load(open(R + "/gpurun_out/pmc_%s_c5box.json" % tag))
 S, K, HW = 64, 30, 256 * 256
-out = {"command": "bash tools/pmc_any.sh <tag> 'k_source_update_box<16>' tools/pmc_run_c5.py  (rocprofv3 --kernel-trace --pmc <set>, separate passes; 64 scenes)",
+out = {"command": "bash tools/pmc_any.sh <tag> 'k_source_update_box<16' tools/pmc_run_c5.py  (rocprofv3 --kernel-trace --pmc <set>, separate passes; 64 scenes)",
        "kernel": pm.get("kernel"), "scenes_per_launch": S, "launches": pm.get("launches"),
        "note": "FETCH_SIZE / WRITE_SIZE in KiB per launch; FETCH_SIZE x 2 on gfx950 for wide coalesced reads (guide, HBM section).  "
                "The kernel's own streams per component: the stepped plane (window rows, GEMM 1) and the previous plane (convergence "
