@@ -15,6 +15,16 @@
 //
 // Partial sums use the layout of engine.h (`partials[S][T][P]`, P = 1 + K B + K (K+1) / 2), so
 // the constraint and convergence kernels that follow are the same as for small K.
+//
+// Round 2: with exact Lipschitz constants and planes of a multiple of 64 pixels the five passes become
+//   k_bigk_lmorph     grid (S)           lambda_max(A^T A): all the morphology step needs
+//   k_bigk_fused      grid (T, S)        passes 1 + 4 in ONE pass over the morphologies on the matrix cores
+//                                        (model, residual, loss, step, d loss/d sed sums; no residual planes)
+//   k_bigk_gram_mfma  grid (T, S)        pass 2 as a GEMM over pixels, one pass instead of one per chunk pair
+//   k_bigk_lipschitz  grid (S)           lambda_max(S S^T) only (sed_only), beside the fused pass on a second stream
+//   k_bigk_sed        grid (S)           SED step + the loss record
+// (scarlet_hip.hip: backward_impl; the chunked passes remain for approximate constants, other plane sizes, the PSF path
+// and behind the NO_BIGK_FUSED / NO_GRAM_MFMA switches).
 #pragma once
 #include "common.h"
 #include "engine.h"

@@ -20,6 +20,8 @@
 //   k_psf_resid   : d = w (render - image), loss partials; writes w d back at padded positions
 //   R2C, k_spec_mul (conj K-hat), C2R          -> G = render^T (w d)
 //   k_grad_psf / k_step_psf : as k_grad / k_step but with G read from the FFT buffer
+// That is the hipFFT chain of round 1 (planes beyond LDS, odd widths).  When the half-spectrum plane fits LDS the chain
+// is k_psf_model4g -> k_psf_conv (fftconv.h) -> k_step_psf4f -> k_sed_step on compact planes: see "three-pass form" below.
 #pragma once
 #include "common.h"
 #include "engine.h"
