@@ -566,3 +566,27 @@ def test_exact_shape_box_instances_are_bit_identical_to_the_generic_ones(BB, B, 
             _lib.set_option("NO_EXACT", 0)
     for x, y in zip(*out):
         np.testing.assert_array_equal(x, y)
+
+
+def test_config5_shape_twelve_iterations_vs_oracle(BB):
+    """BASELINE config 5's shape (6 x 256 x 256, 30 sources, L0) beyond the first iterations: 12 iterations through the
+    one-pass MFMA gradient step, the MFMA Gram matrix on the second stream and the box kernels, against the CPU oracle
+    from the same initial state."""
+    from oracle import pgm
+    from scarlet_amd import synth
+    B, K, H, W, l0 = 6, 30, 256, 256, 0.05
+    scn = synth.make_scene(5003, B=B, H=H, W=W, K=K, min_sep=3)
+    b = BB(scn["images"][None], scn["centers"][None], l0_thresh=l0)
+    b.init_extended(np.ones(B) * 0.1)
+    sed0 = b.sed_current.cpu().numpy()[0]; morph0 = b.morph_current.cpu().numpy()[0]
+    cen0 = b.centers.cpu().numpy()[0]; sh0 = b.shifts.cpu().numpy()[0]
+    iters = 12
+    b.fit(iters, e_rel=0)
+    torch.cuda.synchronize()
+    assert int(b.status.abs().sum().item()) == 0
+    sc = pgm.scene_from_state(scn["images"], sed0, morph0, cen0, sh0, l0_thresh=l0)
+    pgm.fit(sc, iters, e_rel=0)
+    np.testing.assert_array_equal(b.centers[0].cpu().numpy(), np.array([s.center for s in sc.sources]))
+    assert rel_err(b.morph_current[0].cpu().numpy(), np.array([s.morph for s in sc.sources])) < TOL
+    assert rel_err(b.sed_current[0].cpu().numpy(), np.array([s.sed for s in sc.sources])) < TOL
+    assert rel_err(b.mse(0), sc.mse) < TOL

@@ -408,3 +408,36 @@ def test_two_stream_pipeline_equals_single_stream(scarlet):
     for x, y in zip(out[0][:-1], out[1][:-1]):
         assert_array_equal(x, y)
     assert len(np.unique(out[0][2])) > 1          # the run was ragged
+
+
+def test_config3_shape_twenty_five_iterations_vs_oracle(scarlet):
+    """BASELINE config 3's shape beyond the first few iterations: 2 scenes, 25 iterations through the three-pass PSF
+    iteration and the box kernels (exact-shape instances), against the CPU oracle from the same initial state."""
+    from oracle import pgm
+    from scarlet_amd import synth
+    B, H, W, K = 5, 128, 128, 8
+    obs_psfs = np.array([synth.gaussian_psf((41, 41), 1.2 + 0.15 * b) for b in range(B)])
+    model_psf = synth.gaussian_psf((41, 41), 0.9)
+    diff = pgm.match_psfs(obs_psfs.astype(np.float32), model_psf[None].astype(np.float32))
+    scenes = [synth.make_scene(330 + i, B=B, H=H, W=W, K=K, psfs=obs_psfs) for i in range(2)]
+    b = scarlet.BlendBatch(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]),
+                           centroid_weight=model_psf.astype(np.float32))
+    b.set_diff_kernel(diff)
+    scale = (model_psf.max() / obs_psfs.max(axis=(1, 2))).astype(np.float32)
+    b.init_extended(np.ones(B) * 0.1, sed_scale=scale)
+    sed0 = b.sed_current.cpu().numpy(); morph0 = b.morph_current.cpu().numpy()
+    cen0 = b.centers.cpu().numpy(); sh0 = b.shifts.cpu().numpy()
+    iters = 25
+    b.fit(iters, e_rel=0)
+    torch.cuda.synchronize()
+    assert int(b.status.abs().sum().item()) == 0
+    worst = 0
+    for i in range(2):
+        sc = pgm.scene_from_state(scenes[i]["images"], sed0[i], morph0[i], cen0[i], sh0[i],
+                                  diff_kernel=diff, centroid_weight=model_psf.astype(np.float32))
+        pgm.fit(sc, iters, e_rel=0)
+        assert_array_equal(b.centers[i].cpu().numpy(), np.array([s.center for s in sc.sources]))
+        worst = max(worst, rel_err(b.morph_current[i].cpu().numpy(), np.array([s.morph for s in sc.sources])),
+                    rel_err(b.sed_current[i].cpu().numpy(), np.array([s.sed for s in sc.sources])),
+                    rel_err(b.mse(i), sc.mse))
+    assert worst < 1e-5, worst
