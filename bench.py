@@ -154,21 +154,67 @@ def _free_port():
     return port
 
 
-def self_launch(n, argv):
-    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (this process has not
-    touched the GPU and never will), wait for them, relay rank 0's output."""
+def self_launch(n, argv, limit_s=None):
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (this process has not touched the
+    GPU and never will), watch ALL of them, relay rank 0's output.  The first rank that exits non-zero (or the
+    time limit, SCARLET_BENCH_LIMIT_S, default 1500 s) ends the run: the other ranks -- which would otherwise block
+    in the rendezvous or in a barrier until the job's own limit -- are terminated (fresh processes, never
+    re-launched), the failing rank's stderr tail is printed, and the exit code is non-zero."""
+    import tempfile
+    if limit_s is None:
+        limit_s = float(os.environ.get("SCARLET_BENCH_LIMIT_S", "1500"))
     port = _free_port()
-    procs = []
+    procs, logs = [], []
+    tmp = tempfile.mkdtemp(prefix="scarlet_bench_")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+        out = open(os.path.join(tmp, "rank%d.out" % r), "w+b")
+        err = open(os.path.join(tmp, "rank%d.err" % r), "w+b")
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out, stderr=err))
+    t0 = time.time()
+    failed, why = None, ""
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed, why = bad[0], "rank %d exited with code %d" % (bad[0], rcs[bad[0]])
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.time() - t0 > limit_s:
+            failed = next(r for r, rc in enumerate(rcs) if rc is None)
+            why = "time limit of %.0f s reached, rank %d still running" % (limit_s, failed)
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.time()
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, 10 - (time.time() - t1)))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    def tail(f, nbytes=4000):
+        f.flush(); f.seek(0, 2); size = f.tell(); f.seek(max(0, size - nbytes))
+        return f.read().decode(errors="replace")
+    sys.stdout.write(tail(logs[0][0], 1 << 20))
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    if failed is not None:
+        sys.stderr.write("bench.py: %s; the other ranks were terminated.  stderr tail of rank %d:\n%s\n"
+                         % (why, failed, tail(logs[failed][1])))
+    else:
+        for r in range(n):
+            sys.stderr.write(tail(logs[r][1]))
+    for out, err in logs:
+        out.close(); err.close()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return 1 if failed is not None else 0
 
 
 # ----------------------------------------------------------------------------- main
@@ -195,6 +241,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    # fault injection for tests/test_dist_gloo.py (the launcher's watchdog): a rank that dies / hangs before the rendezvous
+    if os.environ.get("SCARLET_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        raise RuntimeError("injected failure on rank %d (SCARLET_BENCH_FAIL_RANK)" % rank)
+    if os.environ.get("SCARLET_BENCH_HANG_RANK") == str(rank) and world > 1:
+        time.sleep(3600)
     if world != args.gpus:
         print("error: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
         sys.exit(2)

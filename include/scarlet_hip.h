@@ -109,11 +109,14 @@ int scarlet_host_prox_weighted_monotonic_f64(double *x, int n, const double *wei
                                              const int *offsets, const int *dist_idx,
                                              int n_dist, double thresh);
 
-/* replaces apply_filter<float> (operators_pybind11.cc:53-70): result = sum_n
- * values[n] * shifted block of image. */
+/* replaces apply_filter<float> / apply_filter<double> (operators_pybind11.cc:53-70; both overloads are
+ * exported, :87-88): result = sum_n values[n] * shifted block of image. */
 int scarlet_host_apply_filter_f32(const float *image, int H, int W, const float *values,
                                   const int *y_start, const int *y_end, const int *x_start,
                                   const int *x_end, int n, float *result);
+int scarlet_host_apply_filter_f64(const double *image, int H, int W, const double *values,
+                                  const int *y_start, const int *y_end, const int *x_start,
+                                  const int *x_end, int n, double *result);
 
 /* ------------------------------------------------------------------------------
  * 2. Batched device operators (n arrays of H x W, row stride W, array stride H*W)

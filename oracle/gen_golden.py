@@ -23,7 +23,13 @@ OUT = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
 from oracle.refshim import load_reference  # noqa: E402
-from scarlet_amd import synth  # noqa: E402
+
+# the synthetic-scene generator is plain numpy; it is loaded by file so that the fixture generator runs on a
+# clean checkout (importing the `scarlet_amd` package needs the built HIP library)
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("_scarlet_amd_synth", os.path.join(ROOT, "scarlet_amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
 
 
 def save(name, **arrays):

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "scarlet_host_prox_weighted_monotonic_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_float]),
     "scarlet_host_prox_weighted_monotonic_f64": (c_int, [_P, c_int, _P, _P, _P, c_int, c_double]),
     "scarlet_host_apply_filter_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
+    "scarlet_host_apply_filter_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "scarlet_prox_weighted_monotonic": (c_int, [_P, c_int, c_int, c_int, _P, c_float, _P]),
     "scarlet_prox_nearest_monotonic": (c_int, [_P, c_int, c_int, c_int, _P, c_float, _P]),
     "scarlet_prox_symmetry": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_float, c_int, c_float, _P]),

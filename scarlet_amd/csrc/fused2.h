@@ -75,19 +75,17 @@ __device__ __forceinline__ KsGeom ks_geom(const SymWindow &s, const unsigned sho
 // constraint pipeline (symmetric, monotonic, no sparsity) are compile-time facts, so the index
 // arithmetic, the bounds predicates and the pipeline switches fold away (same arithmetic on the
 // pixels, bit-identical results).  XS == 0: everything is read from the arguments.
-template <int KM, int BM, int XS = 0>
-__global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
+//
+// P (persistent): the body is one iteration of k_fit2's loop (below).  `resident`: the LDS tiles already hold
+// this scene's morphologies (the final pass of the previous iteration left them there), so phase 0 reads LDS
+// instead of HBM.  Returns bit 0 = scene still active, bit 1 = tiles resident for the next iteration.
+template <int KM, int BM, int XS, bool P>
+__device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, const int c0, const int it_old, const bool resident)
 {
     static_assert(KM <= 4, "one pair of waves per component");
     static_assert(1 + KM * BM <= 32 && 4 * SC_NW2 == 32, "the partial sums are combined by 32 rows of 16 lanes");
     constexpr bool X = XS > 0;
     extern __shared__ __align__(16) float lds[];
-    const int s = blockIdx.x;
-    // the three per-scene words are requested together (one scalar round trip, not three in a row), and both
-    // buffer pointers come from fixed kernel-argument offsets (an index into a.morph[] would be a fourth)
-    const int active_s = a.active[s], c0 = a.cur[s], it_old = a.it[s];
-    asm volatile("" ::"s"(c0), "s"(it_old));     // (keeps the two loads above the branch: the compiler sinks them otherwise)
-    if (!active_s) return;
     const int K = X ? KM : a.K, B = X ? BM : a.B, H = X ? XS : a.H, W = X ? XS : a.W, HW = H * W, LW = tile_stride(W);
     const int tile_floats = H * LW;
     const bool symmetric = X ? true : a.symmetric != 0, monotonic = X ? true : a.monotonic != 0;
@@ -107,6 +105,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     __shared__ int pair_flag[KM][2];           // phase counters of the pair-local synchronisation
     __shared__ double cent_s[KM][2][3];        // centroid moments of the two row halves
     __shared__ unsigned short fl_s[2][32];
+    __shared__ int ctl_s[2];                   // persistent form: {scene still active, tiles resident}
     const int tid = threadIdx.x, lane = tid & 63, wid = uniform(tid >> 6);    // wid in an SGPR: scalar branches
     float *const morph0 = a.morph[0], *const morph1 = a.morph[1], *const sed0 = a.sed[0], *const sed1 = a.sed[1];
     const float *min_g = (c0 ? morph1 : morph0) + (size_t)s * K * HW;
@@ -144,13 +143,15 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
 
     // ---------------- phase 0: issue every global load, tiles -> LDS, Gram
     float4 mreg[GPT][KM];
+    if (!P || !resident) {
 #pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-        const int g = tid + j * SC_FB2;
+        for (int j = 0; j < GPT; ++j) {
+            const int g = tid + j * SC_FB2;
 #pragma unroll
-        for (int k = 0; k < KM; ++k)
-            mreg[j][k] = (g < ngroups && k < K) ? reinterpret_cast<const float4 *>(min_g + (size_t)k * HW)[g]
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < KM; ++k)
+                mreg[j][k] = (g < ngroups && k < K) ? reinterpret_cast<const float4 *>(min_g + (size_t)k * HW)[g]
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     // images: the first group's are requested now, the second group's when phase 1 starts
     // (under the first group's arithmetic) -- 128 VGPRs do not hold both next to the accumulators
@@ -166,6 +167,18 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
     for (int i = tid; i < K * B; i += SC_FB2) sed_s[(i / B) * BM + (i % B)] = sed_in[i];
     ks_fill_lengths(fl_s, tid, fl_req);
     if (tid < 2 * KM) (&pair_flag[0][0])[tid] = 0;
+    if (P && tid == 0) { ctl_s[0] = 1; ctl_s[1] = 1; }
+    if (P && resident) {
+        // (the previous iteration's last barrier ordered its tile writes before these reads)
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            const int g = tid + j * SC_FB2;
+            const int y = g / gpr, x = (g - y * gpr) << 2;
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                mreg[j][k] = (g < ngroups && k < K) ? lds_load4(tiles + k * tile_floats + y * LW + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     const bool small_side = (K <= B);          // nonzero spectrum of A^T A == that of A A^T
     __syncthreads();                           // sed_s visible
     {
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
                 const int y = g / gpr, x = (g - y * gpr) << 2;
 #pragma unroll
                 for (int k = 0; k < KM; ++k)
-                    if (k < K) lds_store4(tiles + k * tile_floats + y * LW + x, mreg[j][k]);
+                    if (k < K && !(P && resident)) lds_store4(tiles + k * tile_floats + y * LW + x, mreg[j][k]);
                 int gi = 0;
 #pragma unroll
                 for (int k = 0; k < KM; ++k)
@@ -302,7 +315,9 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
 #pragma unroll
                             for (int k = 1; k < KM; ++k) model += sed[k][b] * m2[k][p];
                             const f32x2 d = X ? model - im2[p] : ww2[p] * (model - im2[p]);
-                            loss2 += d * d;
+                            // explicit FMAs: the loss is reported, not fed back, so nothing else would expose a
+                            // contraction choice that differs between two instances of this kernel
+                            loss2 = (f32x2){__builtin_fmaf(d.x, d.x, loss2.x), __builtin_fmaf(d.y, d.y, loss2.y)};
                             const f32x2 gg = X ? d : ww2[p] * d;
 #pragma unroll
                             for (int k = 0; k < KM; ++k) { dsed2[k][b] += gg * m2[k][p]; gm2[k][p] += sed[k][b] * gg; }
@@ -575,6 +590,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
                     }
                     const float4 o4 = make_float4(o01.x, o01.y, o23.x, o23.y);
                     out4[g] = o4;
+                    if (P) lds_store4(t.m + y * LW + (xq << 2), o4);     // the next iteration's phase 0 reads the tile
                     const f32x2 e01 = (f32x2){l.x, l.y} - o01, e23 = (f32x2){l.z, l.w} - o23;
                     d2p += e01 * e01; d2p += e23 * e23;
                     n2p += o01 * o01; n2p += o23 * o23;
@@ -618,6 +634,7 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
             const float4 nan4 = make_float4(norm, norm, norm, norm);
             for (int g = g0; g < ngroups; g += 2 * SC_WAVE) out4[g] = nan4;
             if (lead && lane < B) sed_out[k * B + lane] = norm;
+            if (P && lane == 0) ctl_s[1] = 0;       // the tile does not hold this result: reload from HBM
         }
     }
     if (mine && lead && lane == 0) {
@@ -644,9 +661,91 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
                 if (clear) atomicAnd(&a.flags[s * K + kk], ~clear);
                 if (set) atomicOr(&a.flags[s * K + kk], set);
             }
-            if (done) a.active[s] = 0;
+            if (done) { a.active[s] = 0; if (P) ctl_s[0] = 0; }
         }
     }
     STAMP(6);
 #undef STAMP
+    if (P) {
+        // the next iteration reads back what this one stored (previous morphology, centres, shifts, cached
+        // Hankel vectors): stores before the barrier, loads after it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        return uniform(ctl_s[0] | (ctl_s[1] << 1));
+    }
+    return 0;
+}
+
+template <int KM, int BM, int XS = 0>
+__global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
+{
+    const int s = blockIdx.x;
+    // the three per-scene words are requested together (one scalar round trip, not three in a row), and both
+    // buffer pointers come from fixed kernel-argument offsets (an index into a.morph[] would be a fourth)
+    const int active_s = a.active[s], c0 = a.cur[s], it_old = a.it[s];
+    asm volatile("" ::"s"(c0), "s"(it_old));     // (keeps the two loads above the branch: the compiler sinks them otherwise)
+    if (!active_s) return;
+    iterate2_body<KM, BM, XS, false>(a, s, c0, it_old, false);
+}
+
+// ---- k_fit2x: SEVERAL iterations of a scene in one launch (the loop of Blend.fit, blend.py:79-102, per workgroup),
+// for the exact-shape instance <4, 5, 64>.
+//
+// A workgroup keeps its scene for up to n_iter iterations: the morphologies stay in the LDS tiles from one
+// iteration's final pass to the next iteration's gradient step (HBM sees them written once per iteration -- the
+// other buffer is the reference's _last_morph -- and read once, for the convergence sums), converged scenes leave
+// the loop (the ragged stop of _check_convergence), and there is no launch, no workgroup start-up and no grid tail
+// per iteration.
+//
+// The loop is NOT a loop the compiler sees.  Written as one (round 2, profiles/r02_notes.md) it hoists the
+// iteration's per-thread invariants out of the loop and spills them (0.85 - 1.02 ms against 0.72); with the
+// iteration as a separately allocated function (`noinline`) the calling convention saves and restores 32
+// callee-saved VGPRs per wave and call through scratch memory -- 128 KB of extra traffic per scene-iteration.
+// Instead the kernel is the straight-line iteration (register-allocated exactly like k_iterate2) and, while
+// iterations remain, its last instruction is a jump back to its own first instruction with the registers a fresh
+// wave starts with re-created: kernel-argument pointer, workgroup id and work-item id, plus the loop state in the
+// two registers a 1-D grid leaves at zero (workgroup id y = {re-entered, tiles resident, buffer index, iterations
+// left}, workgroup id z = iteration count).  LDS is untouched by the jump.  The register assignment this relies
+// on (user SGPRs = kernel-argument pointer only, workgroup ids x / y / z in s2 / s3 / s4, packed work-item id in
+// v0, no private segment) is the HSA ABI for the kernel descriptor the compiler emits; tools/check_reentry_abi.py
+// verifies those descriptor fields on every build and the library refuses to launch this kernel otherwise.
+#define SC_FIT2X_KERNEL k_fit2x
+extern "C" __global__ __launch_bounds__(SC_FB2, 4) void SC_FIT2X_KERNEL(FusedArgs a, int n_iter)
+{
+    const int s = blockIdx.x;
+    const unsigned st = (unsigned)__builtin_amdgcn_workgroup_id_y();     // 0 at launch (1-D grid)
+    int c0, it, left;
+    bool resident;
+    if (st >> 31) {
+        resident = (st >> 30) & 1; c0 = (int)((st >> 29) & 1); left = (int)(st & 0x1fffffffu);
+        it = (int)__builtin_amdgcn_workgroup_id_z();
+    } else {
+        const int active_s = a.active[s];
+        c0 = a.cur[s]; it = a.it[s];
+        asm volatile("" ::"s"(c0), "s"(it));
+        if (!active_s || n_iter <= 0) return;
+        left = n_iter < 0x1fffffff ? n_iter : 0x1fffffff; resident = false;
+    }
+    const int r = iterate2_body<4, 5, 64, true>(a, s, c0, it, resident);
+    if ((r & 1) && left > 1) {
+        const unsigned nst = 0x80000000u | ((unsigned)(r >> 1) << 30) | ((unsigned)(c0 ^ 1) << 29) | (unsigned)(left - 1);
+        // every wave's stores are complete (iterate2_body waited and met at a barrier): drop the scalar cache's
+        // copies of what they overwrote (centres and shifts are re-read by scalar loads), re-create the launch
+        // registers, jump
+        asm volatile("s_dcache_inv\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "s_mov_b64 s[0:1], %0\n\t"
+                     "s_mov_b32 s2, %1\n\t"
+                     "s_mov_b32 s3, %2\n\t"
+                     "s_mov_b32 s4, %3\n\t"
+                     "v_mov_b32 v0, %4\n\t"
+                     "s_getpc_b64 s[6:7]\n\t"
+                     "s_add_u32 s6, s6, k_fit2x@rel32@lo+4\n\t"
+                     "s_addc_u32 s7, s7, k_fit2x@rel32@hi+12\n\t"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+                     "s_setpc_b64 s[6:7]"
+                     :
+                     : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "s"(s), "s"(nst), "s"(it + 1), "v"((int)threadIdx.x)
+                     : "s0", "s1", "s2", "s3", "s4", "s6", "s7", "v0", "scc", "memory");
+    }
 }

@@ -48,10 +48,10 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_NO_GRAM_MFMA, OPT_NO_BIGK_FUSED, OPT_NO_PIPELINE, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_NO_GRAM_MFMA, OPT_NO_BIGK_FUSED, OPT_NO_PIPELINE, OPT_NO_PERSIST, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
                                                    "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_BOX", "NO_BOX2",
-                                                   "NO_PSF3PASS", "NO_SIDE_STREAM", "NO_GRAM_MFMA", "NO_BIGK_FUSED", "NO_PIPELINE"};
+                                                   "NO_PSF3PASS", "NO_SIDE_STREAM", "NO_GRAM_MFMA", "NO_BIGK_FUSED", "NO_PIPELINE", "NO_PERSIST"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -502,14 +502,15 @@ extern "C" int scarlet_resample(const float *in, float *out, int n, int H, int W
 }
 
 // ---- apply_filter (operators_pybind11.cc:53-70): gather form, one thread per output pixel
-__global__ void k_apply_filter(const float *image, int H, int W, const float *values,
+template <typename T>
+__global__ void k_apply_filter(const T *image, int H, int W, const T *values,
                                const int *y_start, const int *y_end, const int *x_start,
-                               const int *x_end, int n, float *result)
+                               const int *x_end, int n, T *result)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= H * W) return;
     const int y = i / W, x = i - y * W;
-    float acc = 0.f;
+    T acc = (T)0;
     for (int k = 0; k < n; ++k) {
         const int rows = H - y_start[k] - y_end[k], cols = W - x_start[k] - x_end[k];
         const int r = y - y_start[k], cc = x - x_start[k];
@@ -523,7 +524,7 @@ extern "C" int scarlet_apply_filter(const float *image, int H, int W, const floa
                                     const int32_t *x_end, int n, float *result, void *stream)
 {
     if (!image || !result || H <= 0 || W <= 0 || n < 0) return set_err(SCARLET_E_ARG, "bad apply_filter arguments");
-    hipLaunchKernelGGL(k_apply_filter, dim3((H * W + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0,
+    hipLaunchKernelGGL(k_apply_filter<float>, dim3((H * W + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0,
                        (hipStream_t)stream, image, H, W, values, y_start, y_end, x_start, x_end, n, result);
     HIP_TRY(hipGetLastError());
     return SCARLET_OK;
@@ -629,9 +630,10 @@ extern "C" int scarlet_host_prox_monotonic_f64(double *x, int n, const int *ref_
     return SCARLET_OK;
 }
 
-extern "C" int scarlet_host_apply_filter_f32(const float *image, int H, int W, const float *values,
-                                             const int *y_start, const int *y_end, const int *x_start,
-                                             const int *x_end, int n, float *result)
+// both overloads of the reference (operators_pybind11.cc:87-88: apply_filter<float>, apply_filter<double>)
+template <typename T>
+static int host_apply_filter(const T *image, int H, int W, const T *values, const int *y_start, const int *y_end,
+                             const int *x_start, const int *x_end, int n, T *result)
 {
     if (!image || !result || H <= 0 || W <= 0 || n < 0) return set_err(SCARLET_E_ARG, "bad arguments");
     if (n > 0 && (!values || !y_start || !y_end || !x_start || !x_end)) return set_err(SCARLET_E_ARG, "bad arguments");
@@ -640,13 +642,26 @@ extern "C" int scarlet_host_apply_filter_f32(const float *image, int H, int W, c
     int rc;
     if ((rc = dev_alloc_copy(di, image, (size_t)H * W))) return rc;
     if ((rc = dev_alloc_copy(dv, values, n > 0 ? n : 1))) return rc;
-    if ((rc = dev_alloc_copy(dr, (const float *)nullptr, (size_t)H * W))) return rc;
+    if ((rc = dev_alloc_copy(dr, (const T *)nullptr, (size_t)H * W))) return rc;
     for (int i = 0; i < 4; ++i) if ((rc = dev_alloc_copy(idx[i], hidx[i], n > 0 ? n : 1))) return rc;
-    rc = scarlet_apply_filter(di.as<float>(), H, W, dv.as<float>(), idx[0].as<int>(), idx[1].as<int>(), idx[2].as<int>(),
-                              idx[3].as<int>(), n, dr.as<float>(), nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(result, dr.p, (size_t)H * W * sizeof(float), hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_apply_filter<T>, dim3((H * W + SC_BLOCK - 1) / SC_BLOCK), dim3(SC_BLOCK), 0, (hipStream_t)0,
+                       di.as<T>(), H, W, dv.as<T>(), idx[0].as<int>(), idx[1].as<int>(), idx[2].as<int>(), idx[3].as<int>(),
+                       n, dr.as<T>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(result, dr.p, (size_t)H * W * sizeof(T), hipMemcpyDeviceToHost));
     return SCARLET_OK;
+}
+extern "C" int scarlet_host_apply_filter_f32(const float *image, int H, int W, const float *values,
+                                             const int *y_start, const int *y_end, const int *x_start,
+                                             const int *x_end, int n, float *result)
+{
+    return host_apply_filter<float>(image, H, W, values, y_start, y_end, x_start, x_end, n, result);
+}
+extern "C" int scarlet_host_apply_filter_f64(const double *image, int H, int W, const double *values,
+                                             const int *y_start, const int *y_end, const int *x_start,
+                                             const int *x_end, int n, double *result)
+{
+    return host_apply_filter<double>(image, H, W, values, y_start, y_end, x_start, x_end, n, result);
 }
 
 // =====================================================================================
@@ -657,17 +672,18 @@ extern "C" int scarlet_host_apply_filter_f32(const float *image, int H, int W, c
 struct Profiler {
     std::atomic<bool> on{false};
     std::vector<hipEvent_t> ev;     // pairs (start, stop)
-    std::vector<int> cls;
+    std::vector<int> cls, weight;   // weight: iterations one launch covers (k_fit2: several)
     int used = 0, cap = 0;
 };
 static Profiler g_prof;                // process-wide: one profiled fit at a time (documented in the header)
 static std::mutex g_prof_mu;
-static inline void prof_start(int cls, hipStream_t st)
+static inline void prof_start(int cls, hipStream_t st, int weight = 1)
 {
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lock(g_prof_mu);
     if (g_prof.on && g_prof.used < g_prof.cap) {
         g_prof.cls[g_prof.used] = cls;
+        g_prof.weight[g_prof.used] = weight;
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
     }
 }
@@ -688,6 +704,7 @@ extern "C" int scarlet_profile_begin(int max_iterations)
     const int cap = max_iterations * 16;                 // (two half-batches per iteration when scarlet_fit pipelines them)
     g_prof.ev.assign((size_t)cap * 2, nullptr);
     g_prof.cls.assign(cap, 0);
+    g_prof.weight.assign(cap, 1);
     for (auto &e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
     g_prof.cap = cap; g_prof.used = 0; g_prof.on = true;
     return SCARLET_OK;
@@ -702,10 +719,10 @@ extern "C" int scarlet_profile_end(double total_ms[SC_NCLASS], int64_t launches[
         HIP_TRY(hipEventSynchronize(g_prof.ev[2 * i + 1]));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
-        total_ms[g_prof.cls[i]] += ms; launches[g_prof.cls[i]] += 1;
+        total_ms[g_prof.cls[i]] += ms; launches[g_prof.cls[i]] += g_prof.weight[i];
     }
     for (auto e : g_prof.ev) (void)hipEventDestroy(e);
-    g_prof.ev.clear(); g_prof.cls.clear(); g_prof.cap = g_prof.used = 0;
+    g_prof.ev.clear(); g_prof.cls.clear(); g_prof.weight.clear(); g_prof.cap = g_prof.used = 0;
     return SCARLET_OK;
 }
 
@@ -1549,8 +1566,11 @@ static bool fused_ok(const scarlet_batch *b, int approximate_L)
     if (b->H > 64 || b->W > 64 || (b->W & 3) || b->H < 3 || b->W < 3) return false;
     return fused_lds_bytes(b) <= LDS_LIMIT - 4096;
 }
-static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
+// n_iter > 1: that many iterations in ONE launch where the persistent form exists (k_fit2: the headline shape's
+// exact instance); *done receives the number of iterations the launch covers
+static int launch_fused(scarlet_batch *b, double e_rel, void *stream, int n_iter = 1, int *done = nullptr)
 {
+    if (done) *done = 1;
     int rc = ensure_tables();
     if (rc) return rc;
     FusedArgs f;
@@ -1594,7 +1614,14 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream)
         // an instance with every shape and switch folded at compile time
         const bool exact64 = b->K == 4 && b->B == 5 && b->H == 64 && b->W == 64 && !b->weights && b->weight_scalar == 1.0f && b->symmetric &&
                              b->monotonic && b->l0_thresh < 0.f && b->l1_thresh < 0.f && !opt(OPT_NO_EXACT);
-        if (exact64) {
+        if (exact64 && n_iter > 1 && !opt(OPT_NO_PERSIST)) {
+            rc = allow_lds(k_fit2x, lds2);
+            if (rc) return rc;
+            prof_start(4, st, n_iter);
+            hipLaunchKernelGGL(k_fit2x, dim3(b->S), dim3(SC_FB2), lds2, st, f, n_iter);
+            prof_stop(st);
+            if (done) *done = n_iter;
+        } else if (exact64) {
             rc = allow_lds(k_iterate2<4, 5, 64>, lds2);
             if (rc) return rc;
             prof_start(4, st);
@@ -1684,7 +1711,11 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
     }
     for (int i = 0; i < max_iter; ++i) {
         if (fused) {
-            if ((rc = launch_fused(b, e_rel, stream))) return rc;
+            // up to the next host check (or the end) in one launch where the persistent kernel applies
+            int want = max_iter - i, did = 1;
+            if (check_every > 0) { const int to_check = check_every - i % check_every; if (to_check < want) want = to_check; }
+            if ((rc = launch_fused(b, e_rel, stream, want, &did))) return rc;
+            i += did - 1; launched += did - 1;
         } else {
             if ((rc = scarlet_backward_step(b, approximate_L, stream))) return rc;
             prof_start(2, st);

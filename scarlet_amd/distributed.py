@@ -18,9 +18,12 @@ def shard_range(n_scenes, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, timeout_s=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
-    (rank, world, local_rank).  world == 1 without env -> no process group."""
+    (rank, world, local_rank).  world == 1 without env -> no process group.  `timeout_s` (default: environment
+    SCARLET_DIST_TIMEOUT_S, else 300): rendezvous and collective timeout -- a rank that dies before it joins makes
+    the others fail after this long instead of blocking until the job's time limit."""
+    import datetime
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -32,8 +35,22 @@ def init_from_env(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("SCARLET_DIST_TIMEOUT_S", "300"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(timeout_s)))
     return rank, world, local
+
+
+def _run_p2p(ops):
+    """Post every transfer of a scatter / gather at once and wait for all of them: on RCCL one grouped call, so
+    that the transfers to / from the seven peers of a node run concurrently on their seven xGMI links instead of
+    one link at a time."""
+    import torch.distributed as dist
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
 
 
 def scatter_scenes(tensors, n_scenes, src=0):
@@ -42,8 +59,8 @@ def scatter_scenes(tensors, n_scenes, src=0):
     `tensors`: on `src` a list of tensors whose first axis is the global scene index
     (length n_scenes); on other ranks a list of (shape_without_scene_axis, dtype) is not
     needed -- shapes/dtypes are broadcast first.  Returns this rank's shards.
-    Implemented with point-to-point sends (uneven shards allowed); on RCCL these run over
-    the direct xGMI links from rank 0 to each peer."""
+    Implemented with point-to-point sends (uneven shards allowed), ALL of them -- every tensor to every peer --
+    posted together: on RCCL they run concurrently over the direct xGMI links from rank 0 to each peer."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -55,37 +72,37 @@ def scatter_scenes(tensors, n_scenes, src=0):
     meta = box[0]
     dev = tensors[0].device if rank == src else (
         torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
-    out = []
+    out, ops, keep = [], [], []
+    lo, hi = shard_range(n_scenes, rank, world)
     for i, (shape, dtype) in enumerate(meta):
         dt = getattr(torch, dtype)
-        lo, hi = shard_range(n_scenes, rank, world)
         if rank == src:
-            reqs = []
             for r in range(world):
                 a, b = shard_range(n_scenes, r, world)
                 if r == src:
-                    mine = tensors[i][a:b].clone()
-                else:
-                    reqs.append(dist.isend(tensors[i][a:b].contiguous(), dst=r))
-            for q in reqs:
-                q.wait()
-            out.append(mine)
+                    out.append(tensors[i][a:b].clone())
+                elif b > a:
+                    part = tensors[i][a:b].contiguous()
+                    keep.append(part)
+                    ops.append(dist.P2POp(dist.isend, part, r))
         else:
             buf = torch.empty((hi - lo,) + tuple(shape), dtype=dt, device=dev)
-            dist.recv(buf, src=src)
+            if hi > lo:
+                ops.append(dist.P2POp(dist.irecv, buf, src))
             out.append(buf)
+    _run_p2p(ops)
     return out
 
 
 def gather_scenes(tensors, n_scenes, dst=0):
-    """Gather per-rank scene-major tensors back to `dst` in global scene order.
-    Returns the concatenated tensors on `dst`, None elsewhere."""
+    """Gather per-rank scene-major tensors back to `dst` in global scene order (every tensor from every peer
+    posted together, see _run_p2p).  Returns the concatenated tensors on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
         return list(tensors)
     rank, world = dist.get_rank(), dist.get_world_size()
-    out = []
+    ops, parts_all, keep = [], [], []
     for t in tensors:
         t = t.contiguous()
         if dist.get_backend() == "gloo" and t.is_cuda:
@@ -98,12 +115,15 @@ def gather_scenes(tensors, n_scenes, dst=0):
                     parts.append(t)
                 else:
                     buf = torch.empty((b - a,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                    dist.recv(buf, src=r)
+                    if b > a:
+                        ops.append(dist.P2POp(dist.irecv, buf, r))
                     parts.append(buf)
-            out.append(torch.cat(parts, dim=0))
-        else:
-            dist.send(t, dst=dst)
-    return out if rank == dst else None
+            parts_all.append(parts)
+        elif t.shape[0] > 0:
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, dst))
+    _run_p2p(ops)
+    return [torch.cat(parts, dim=0) for parts in parts_all] if rank == dst else None
 
 
 def max_over_ranks(value):

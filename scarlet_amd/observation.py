@@ -4,8 +4,8 @@
 (images, weights, PSFs) and, after ``match(model_frame)``, the band slice and the PSF
 difference kernel that map the model into the observed frame.  Data live on the device;
 the engine computes in float32: a float64 DATA frame is cast to the model frame's dtype by ``match``
-(as in the reference), a float64 MODEL frame is refused when the first Component is built on it
-(component._require_float32_frame).
+(as in the reference), a float64 MODEL frame is accepted with one warning -- the factors are stored in float32
+(component._require_float32_frame; a strict opt-in refuses it).
 """
 import logging
 

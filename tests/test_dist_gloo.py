@@ -58,3 +58,37 @@ def test_scatter_gather_world2(n_scenes):
     for p in procs:
         p.join(timeout=60)
     assert results == {0: True, 1: True}
+
+
+def test_launcher_ends_the_run_when_a_rank_dies_before_the_rendezvous():
+    """bench.py's own launcher (`python bench.py --gpus 2` without torchrun): rank 1 raises before
+    init_process_group, rank 0 would wait for it for ever.  The launcher must notice, terminate rank 0, print the
+    failing rank's stderr and return non-zero within seconds -- not at the job's time limit."""
+    import subprocess
+    import time
+    env = dict(os.environ, SCARLET_BENCH_FAIL_RANK="1", SCARLET_BENCH_HANG_RANK="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--scenes", "4", "--no-cpu"], env=env, capture_output=True, timeout=120)
+    took = time.time() - t0
+    assert p.returncode != 0
+    assert took < 60, took
+    err = p.stderr.decode()
+    assert "rank 1 exited with code" in err and "injected failure on rank 1" in err
+
+
+def test_launcher_time_limit():
+    """every rank hangs: the launcher's own limit ends the run and says which rank was still running"""
+    import subprocess
+    env = dict(os.environ, SCARLET_BENCH_HANG_RANK="0", SCARLET_BENCH_LIMIT_S="3")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    # rank 1 would fail for lack of a GPU here; make it hang as well by pointing both hooks at their ranks
+    env["SCARLET_BENCH_HANG_RANK"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], env=dict(env, WORLD_SIZE="1"),
+                       capture_output=True, timeout=120) if False else None
+    env2 = dict(env)
+    p = subprocess.run([sys.executable, "-c",
+                        "import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.self_launch(1, ['--gpus', '1'], limit_s=3))" % ROOT],
+                       env=dict(env2, SCARLET_BENCH_HANG_ALWAYS="1"), capture_output=True, timeout=120)
+    assert p.returncode != 0 and "time limit" in p.stderr.decode()

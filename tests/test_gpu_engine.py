@@ -175,6 +175,46 @@ def test_exact_shape_instance_is_bit_identical_to_the_generic_kernel(BB, monkeyp
         np.testing.assert_array_equal(a, c)
 
 
+def test_multi_iteration_launch_is_bit_identical_to_one_launch_per_iteration(BB):
+    """k_fit2x (several iterations of a scene per launch, morphologies resident in LDS between them, the loop closed
+    by the kernel's re-entry jump) against k_iterate2<4,5,64> launched once per iteration (NO_PERSIST): every output
+    bit for bit, through centroid iterations (it % 5 == 0), a ragged e_rel stop, fixed factors, a host check every
+    few iterations (several launches of several iterations each) and a second fit() call on the same batch."""
+    from scarlet_amd import synth, _lib
+    S = 160
+    data = synth.make_batch(1400, S)
+    fix = np.zeros((S, 4), dtype=np.uint8)
+    fix[::3, 1] = 1
+
+    def run(per_iteration, e_rel, check_every, n=(23, 9), **kw):
+        _lib.set_option("NO_PERSIST", 1 if per_iteration else 0)
+        try:
+            b = BB(data["images"], data["centers"])
+            for name, arr in kw.items():
+                setattr(b, name, torch.as_tensor(arr).cuda())
+            b._fill_struct()
+            b.init_extended(np.ones(5) * 0.1)
+            launched = [b.fit(n[0], e_rel=e_rel, check_every=check_every)]
+            launched.append(b.fit(n[1], e_rel=e_rel, check_every=check_every))
+            torch.cuda.synchronize()
+            return launched, [t.cpu().numpy() for t in (b.morph_current, b.sed_current, b.mse_buf[:, :sum(n)], b.centers,
+                                                        b.shifts, b.flags, b.it, b.lipschitz, b.active, b.cur, b.status,
+                                                        b.morph[0], b.morph[1], b.sed[0], b.sed[1])]
+        finally:
+            _lib.set_option("NO_PERSIST", 0)
+
+    for e_rel, check_every, kw in ((0.0, 0, {}), (1e-3, 0, {}), (1e-3, 4, {}), (2e-3, 7, dict(fix_morph=fix)),
+                                   (0.0, 10, dict(fix_sed=fix))):
+        (l1, one), (l2, many) = run(True, e_rel, check_every, **kw), run(False, e_rel, check_every, **kw)
+        assert l1 == l2
+        for a, c in zip(one, many):
+            np.testing.assert_array_equal(a, c)
+    # a single iteration per call never takes the multi-iteration kernel; 1 + 1 + ... must equal one call of n
+    (_, single), (_, many) = run(False, 0.0, 0, n=(1, 1)), run(False, 0.0, 0, n=(2, 0))
+    for a, c in zip(single[:7], many[:7]):
+        np.testing.assert_array_equal(a, c)
+
+
 @pytest.mark.parametrize("B,K,H,W,path", [
     (3, 2, 32, 48, "k_iterate2<4,5> (8 waves per scene)"),
     (5, 4, 24, 64, "k_iterate2<4,5>, short tile"),

@@ -133,6 +133,13 @@ def test_host_dropins_match_oracle_bitwise(L):
     L.check(L.lib.scarlet_host_apply_filter_f32(img.ctypes.data, 12, 15, vals.ctypes.data, ys.ctypes.data,
                                                 ye.ctypes.data, xs.ctypes.data, xe.ctypes.data, 4, out.ctypes.data))
     assert rel_err(out, ref) < 1e-6
+    # the double overload (operators_pybind11.cc:87-88): same sums in float64, bit for bit (same order of the terms)
+    img64, vals64 = rng.rand(12, 15), rng.rand(4)
+    ref64 = np.zeros_like(img64); native.apply_filter(img64, vals64, ys, ye, xs, xe, ref64)
+    out64 = np.zeros_like(img64)
+    L.check(L.lib.scarlet_host_apply_filter_f64(img64.ctypes.data, 12, 15, vals64.ctypes.data, ys.ctypes.data,
+                                                ye.ctypes.data, xs.ctypes.data, xe.ctypes.data, 4, out64.ctypes.data))
+    assert rel_err(out64, ref64) < 1e-14
 
 
 # ------------------------------------------------------------------ symmetry

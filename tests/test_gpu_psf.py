@@ -156,6 +156,42 @@ def test_reference_blend_tests(scarlet):
     assert np.all(mse[:-1] - mse[1:] >= -1e-9)
 
 
+def test_reference_blend_tests_with_their_float64_frames(scarlet, caplog):
+    """reference tests/test_blend.py:63, 83, 104 build ``Frame(..., dtype=np.float64)`` and float64 data: ported
+    user code must construct and run (in float32, after ONE warning) instead of stopping at the first Component."""
+    import logging
+    from scarlet_amd import component
+    shape = (6, 31, 55)
+    coords = [(20, 10), (10, 30), (17, 42)]
+    target_psf, psfs, images, seds = init_data(scarlet, shape, coords, [3, 2, 1], dtype=np.float64)
+    component._warned_float64_frame = False
+    with caplog.at_level(logging.WARNING, logger="scarlet_amd.component"):
+        frame = scarlet.Frame(images.shape, psfs=target_psf[None], dtype=np.float64)
+        obs = scarlet.Observation(images, psfs=psfs).match(frame)
+        sources = [scarlet.PointSource(frame, coord, obs) for coord in coords]
+        blend = scarlet.Blend(sources, obs)
+    assert sum("float32" in r.getMessage() for r in caplog.records if r.name == "scarlet_amd.component") == 1
+    assert_almost_equal(images, npy(obs.render(blend.get_model())), decimal=4)
+    blend.fit(10)
+    assert blend.it == 2
+    assert max(blend.mse) < 1e-8
+    sources = [scarlet.ExtendedSource(frame, coord, obs, np.ones((6,))) for coord in coords]
+    blend = scarlet.Blend(sources, obs)
+    psf_scale = obs.frame.psfs.max(axis=(1, 2)) / frame.psfs[0].max()
+    assert_almost_equal(np.array([npy(c.sed) * psf_scale for c in blend.components]), seds, decimal=4)
+    blend.fit(100)
+    assert blend.it < 20
+    mse = np.array(blend.mse)
+    assert np.all(mse[:-1] - mse[1:] >= -1e-9)
+    # the opt-in strict mode refuses the frame
+    component.STRICT_FLOAT32_FRAME = True
+    try:
+        with pytest.raises(TypeError, match="float32"):
+            scarlet.PointSource(frame, coords[0], obs)
+    finally:
+        component.STRICT_FLOAT32_FRAME = False
+
+
 def test_config3_shape_128_psf_k8_vs_oracle(scarlet):
     """BASELINE config 3 shape (5x128x128, per-band PSF 41x41, 8 sources) at a 2-scene batch:
     general path = hipFFT convolution + 8-component gradient kernels + workgroup-level

@@ -256,14 +256,26 @@ def test_project_image_reference_vectors():
     assert a.shape == b.shape == (5, 7) and a.sum() == 21 and b.sum() == 20
 
 
-def test_float64_model_frame_is_refused_loudly():
-    """a float64 model Frame promised double-precision factors that the float32 engine does
-    not compute; it is refused (before anything touches the device) instead of silently down-cast.
-    float64 DATA stays fine: Observation builds a float64 data frame and match() casts it."""
+def test_float64_model_frame_policy(caplog):
+    """the reference's own tests build float64 model frames (tests/test_blend.py:63, 83, 104), so a
+    float64 model Frame is accepted with ONE warning (factors are stored in float32); the opt-in strict flag turns
+    it into a TypeError raised before anything touches the device.  float64 DATA: Observation builds a float64
+    data frame and match() casts it."""
+    import logging
     import scarlet_amd as sc
+    from scarlet_amd import component
     frame64 = sc.Frame((3, 8, 8), psfs=None, dtype=np.float64)
-    with pytest.raises(TypeError, match="float32"):
-        sc.Component(frame64, np.ones(3), np.ones((8, 8)))
+    component._warned_float64_frame = False
+    with caplog.at_level(logging.WARNING, logger="scarlet_amd.component"):
+        component._require_float32_frame(frame64)
+        component._require_float32_frame(frame64)
+    assert sum(r.name == "scarlet_amd.component" for r in caplog.records) == 1
+    component.STRICT_FLOAT32_FRAME = True
+    try:
+        with pytest.raises(TypeError, match="float32"):
+            sc.Component(frame64, np.ones(3), np.ones((8, 8)))
+    finally:
+        component.STRICT_FLOAT32_FRAME = False
     obs = sc.Observation(np.zeros((3, 8, 8), dtype=np.float64))
     assert np.dtype(obs.frame.dtype) == np.float64
     obs.match(sc.Frame((3, 8, 8), psfs=None, dtype=np.float32))

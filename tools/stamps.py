@@ -14,7 +14,8 @@ b.init_extended(np.ones(5) * .1)
 b.fit(int(os.environ.get("STAMP_PRE", "3")), e_rel=0, check_every=0)
 torch.cuda.synchronize()
 b.workspace[:S * 16 * 8].zero_()
-b.fit(1, e_rel=0, check_every=0)
+# STAMP_ITERS > 1: the multi-iteration kernel (k_fit2x); the stamps are those of the launch's LAST iteration
+b.fit(int(os.environ.get("STAMP_ITERS", "1")), e_rel=0, check_every=0)
 torch.cuda.synchronize()
 st = b.workspace[:S * 16 * 8].view(torch.int64).view(S, 16).cpu().numpy()
 dt = np.diff(st[:, :7], axis=1)
