@@ -81,6 +81,42 @@ def psf_setup(B):
     return obs, model
 
 
+# ----------------------------------------------------------------------------- host cores
+def host_cores():
+    """What this process may use of the host: CPUs in its affinity mask, physical cores among them (one per
+    (package, core id): SMT siblings counted once), and the cgroup CPU quota if one is set.  The CPU leg runs one
+    process per physical core, capped by the quota (processes beyond the quota would only time-slice)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    cores, topo = set(), True
+    for c in cpus:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            cores.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            topo = False
+            break
+    physical = len(cores) if topo and cores else len(cpus)
+    quota = None
+    try:                                           # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                       # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    use = physical if quota is None else max(1, min(physical, int(quota)))
+    return dict(os_cpu_count=os.cpu_count(), affinity_cpus=len(cpus), physical_cores=physical,
+                smt_detected=bool(topo and physical < len(cpus)), cgroup_cpu_quota=quota, cores_used=use)
+
+
 # ----------------------------------------------------------------------------- host workers
 def _gen_chunk(args):
     from scarlet_amd import synth
@@ -139,10 +175,10 @@ def cpu_baseline(pool, workers, scenes_per_worker, iters, kw, psf, l0, first):
     busy = max(r[1] for r in res)      # aggregate rate over the cores actually used
     return dict(value=n / busy, unit="scene-iterations/s", cores=workers, kind="port",
                 one_core=dict(value=n1 / s1, unit="scene-iterations/s", cores=1),
-                os_cpu_count=os.cpu_count(),
+                os_cpu_count=os.cpu_count(), host=host_cores(),
                 sample="%d scenes x %d iterations of the same workload per process, CPU oracle (numpy + C sweep), "
-                       "%d processes (all-core figure) and 1 process (one_core), fit() time only (wall %.1f s)"
-                       % (scenes_per_worker, iters, workers, wall))
+                       "%d processes = one per physical core this job may use (`value`) and 1 process (one_core), "
+                       "fit() time only (wall %.1f s)" % (scenes_per_worker, iters, workers, wall))
 
 
 # ----------------------------------------------------------------------------- launcher
@@ -217,6 +253,31 @@ def self_launch(n, argv, limit_s=None):
     return 1 if failed is not None else 0
 
 
+# ----------------------------------------------------------------------------- the other BASELINE configs
+def run_other_configs(args):
+    """The default single-GPU run also times BASELINE configs[2] (c3) and configs[4] (c5), each in a fresh child
+    process started BEFORE this process touches the GPU (same script, `--config c3|c5`, a few seconds each), and
+    embeds their JSON lines under "other_configs".  A failure is recorded, it does not fail the headline."""
+    out = {}
+    for cfg, steps, warm in (("c3", min(args.steps, 10), min(args.warmup, 3)), ("c5", min(args.steps, 10), min(args.warmup, 3))):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", str(warm)]
+        if args.no_cpu:
+            cmd.append("--no-cpu")
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, timeout=900)
+            line = [l for l in p.stdout.decode().splitlines() if l.startswith('{"metric"')]
+            if p.returncode == 0 and line:
+                d = json.loads(line[-1])
+                d["bench_wall_s"] = time.perf_counter() - t0
+                out[cfg] = d
+            else:
+                out[cfg] = {"error": "exit code %d: %s" % (p.returncode, p.stderr.decode()[-400:])}
+        except subprocess.TimeoutExpired:
+            out[cfg] = {"error": "timed out after 900 s"}
+    return out
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -228,6 +289,8 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: `scenes` in total, generated on rank 0 and scattered over RCCL")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-other", action="store_true",
+                    help="headline workload only (the default single-GPU c2 run also times c3 and c5 in child processes)")
     ap.add_argument("--cpu-scenes", type=int, default=None, help="oracle scenes per host process")
     ap.add_argument("--cpu-iters", type=int, default=None)
     ap.add_argument("--no-symmetric", action="store_true", help="ablation: drop the symmetry constraint")
@@ -249,6 +312,10 @@ def main():
     if world != args.gpus:
         print("error: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
         sys.exit(2)
+    other = None
+    if (args.config == "c2" and world == 1 and not args.no_other and not args.strong and args.scenes is None
+            and not args.no_symmetric and not args.no_monotonic):
+        other = run_other_configs(args)
     cfg = CONFIGS[args.config]
     B, H, W, K = cfg["B"], cfg["H"], cfg["W"], cfg["K"]
     S_arg = args.scenes if args.scenes is not None else cfg["S"]
@@ -257,8 +324,12 @@ def main():
 
     # ---- host-side work first, in forked workers, BEFORE this process loads the HIP library
     import multiprocessing as mp
-    share = max(1, (os.cpu_count() or 1) // max(1, world))
-    workers = max(1, min(16, share))
+    # one worker process per physical core this job may use (affinity mask, SMT siblings once, cgroup quota),
+    # shared between the ranks of a multi-GPU run; SCARLET_BENCH_WORKERS overrides
+    hc = host_cores()
+    workers = max(1, hc["cores_used"] // max(1, world))
+    if os.environ.get("SCARLET_BENCH_WORKERS"):
+        workers = max(1, int(os.environ["SCARLET_BENCH_WORKERS"]))
     pool = mp.get_context("fork").Pool(workers)
     cpu = None
     images = centers = None
@@ -348,8 +419,9 @@ def main():
     elapsed = time.perf_counter() - t0
     import ctypes
     ms = (ctypes.c_double * 8)()
-    cnt = (ctypes.c_int64 * 8)()
-    _lib.check(_lib.lib.scarlet_profile_end(ms, cnt))
+    cnt = (ctypes.c_int64 * 8)()            # iterations covered by the class's launches
+    raw = (ctypes.c_int64 * 8)()            # kernel launches (k_fit2x: one launch covers several iterations)
+    _lib.check(_lib.lib.scarlet_profile_end_ex(ms, cnt, raw))
     assert launched == args.steps
     elapsed = distributed.max_over_ranks(elapsed)
     n_active = int(batch.active.sum().item())
@@ -392,6 +464,8 @@ def main():
         kernel_label = "k_iterate2<4,5,0>" if (K <= 4 and B <= 5 and not os.environ.get("SCARLET_FUSED_V1")) else "k_iterate"
         if kernel_label.startswith("k_iterate2") and (K, B, H, W) == (4, 5, 64, 64) and not os.environ.get("SCARLET_NO_EXACT"):
             kernel_label = "k_iterate2<4,5,64>"        # the exact-shape instance (default pipeline, unit weights)
+            if raw[dom] < cnt[dom]:
+                kernel_label = "k_fit2x"               # the same iteration, several per launch (fused2.h)
     elif dom == 5:
         kernel_label = "k_psf_conv (render + adjoint, LDS-resident FFT)" if not os.environ.get("SCARLET_PSF_HIPFFT") else "psf_chain (hipFFT)"
     elif dom == 2:
@@ -427,6 +501,7 @@ def main():
         "config": {"workload": cfg["label"] % S0 + (" -- STRONG scaling: %d scenes in total" % S_total if args.strong else ""),
                    "config": args.config, "scenes_per_gpu": S0, "scenes_total": S_total,
                    "bands": B, "height": H, "width": W, "sources": K,
+                   "unique_scenes": int(min(S0, cfg["unique"] or S0)),
                    "parallelism": "scenes sharded, %d rank(s), no collective in the iteration" % world,
                    "batch_iterations_per_s": args.steps / elapsed,
                    "active_scenes_after_timed_region": n_active, "scenes_with_status": status_bad,
@@ -437,15 +512,20 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kernel_label, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": bytes_unit * S_launch, "avg_launch_ms": avg_ms,
+                     "algorithmic_bytes_per_launch": bytes_unit * S_launch * (cnt[dom] // max(1, raw[dom])),
+                     "algorithmic_bytes_per_launch_and_iteration": bytes_unit * S_launch,
+                     "avg_launch_ms": avg_ms * (cnt[dom] // max(1, raw[dom])), "avg_ms_per_iteration_in_launch": avg_ms,
+                     "iterations_per_launch": cnt[dom] // max(1, raw[dom]), "launches": int(raw[dom]),
                      "launches_per_iteration_in_class": launches_per_iter, "scenes_per_launch": S_launch,
                      "pipelines": pipelines,
                      "per_class_avg_ms": per_class,
                      "whole_iteration_frac": bytes_unit * S0 / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    if other is not None:
+        out["other_configs"] = other
     if cpu is not None:
         out["cpu_baseline"] = cpu
-        out["config"]["gpu_over_cpu_all_cores"] = value / cpu["value"]
+        out["config"]["gpu_over_cpu_%d_cores" % cpu["cores"]] = value / cpu["value"]
         out["config"]["gpu_over_cpu_one_core"] = value / cpu["one_core"]["value"]
     print(json.dumps(out))
 

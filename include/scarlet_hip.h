@@ -318,6 +318,10 @@ int scarlet_check_convergence(scarlet_batch *b, double e_rel, void *stream);
  * the summed milliseconds and launch counts, and stop recording. */
 int scarlet_profile_begin(int max_iterations);
 int scarlet_profile_end(double total_ms[8], int64_t launches[8]);
+/* the same with both counts: `iterations` = iterations covered by the class's launches (what
+ * scarlet_profile_end reports as `launches`: a k_fit2x launch covers several), `launches` = kernel
+ * launches actually recorded.  Either array may be NULL. */
+int scarlet_profile_end_ex(double total_ms[8], int64_t iterations[8], int64_t launches[8]);
 
 /* ExtendedSource initialisation on device (source.py:139-180, rank f1 of SURVEY 8f):
  * per component: pixel SED (optionally PSF-corrected by the caller through sed_scale

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "scarlet_check_convergence": (c_int, [POINTER(ScarletBatch), c_double, _P]),
     "scarlet_profile_begin": (c_int, [c_int]),
     "scarlet_profile_end": (c_int, [_P, _P]),
+    "scarlet_profile_end_ex": (c_int, [_P, _P, _P]),
     "scarlet_init_extended": (c_int, [POINTER(ScarletBatch), _P, c_float, _P, c_int, c_int, c_int, _P]),
     "scarlet_convergence_sums": (c_int, [POINTER(ScarletBatch), _P]),
     "scarlet_batch_prepare_psf": (c_int, [POINTER(ScarletBatch), _P]),

@@ -76,11 +76,21 @@ __device__ __forceinline__ KsGeom ks_geom(const SymWindow &s, const unsigned sho
 // arithmetic, the bounds predicates and the pipeline switches fold away (same arithmetic on the
 // pixels, bit-identical results).  XS == 0: everything is read from the arguments.
 //
-// P (persistent): the body is one iteration of k_fit2's loop (below).  `resident`: the LDS tiles already hold
-// this scene's morphologies (the final pass of the previous iteration left them there), so phase 0 reads LDS
-// instead of HBM.  Returns bit 0 = scene still active, bit 1 = tiles resident for the next iteration.
+// P (persistent): the body is one iteration of k_fit2x's loop (below).  `reentered`: not the launch's first
+// iteration of this scene; `resident`: the LDS tiles already hold this scene's morphologies (the final pass of
+// the previous iteration left them there), so phase 0 reads LDS instead of HBM.  Returns bit 0 = scene still
+// active, bit 1 = tiles resident for the next iteration.
+//
+// What one iteration hands to the next inside a launch travels through LDS (tiles, SEDs, centres, shifts), never
+// through a global store followed by a cached global load: the CU's vector L1 can still hold the line from the
+// PREVIOUS iteration's load of the same address (centres, shifts: re-read every iteration; measured: ~1 % of the
+// scenes of a 10 000-scene launch then started an iteration from a stale centre or SED), and nothing short of an
+// L1 invalidate per iteration (buffer_inv, ~2 us) repairs that.  The two streams that must come back from memory
+// -- the previous morphology for the convergence sums, the cached Hankel vectors -- are loaded past the L1
+// (non-temporal loads, L2-served).
 template <int KM, int BM, int XS, bool P>
-__device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, const int c0, const int it_old, const bool resident)
+__device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, const int c0, const int it_old, const bool resident,
+                                             const bool reentered = false)
 {
     static_assert(KM <= 4, "one pair of waves per component");
     static_assert(1 + KM * BM <= 32 && 4 * SC_NW2 == 32, "the partial sums are combined by 32 rows of 16 lanes");
@@ -105,7 +115,10 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     __shared__ int pair_flag[KM][2];           // phase counters of the pair-local synchronisation
     __shared__ double cent_s[KM][2][3];        // centroid moments of the two row halves
     __shared__ unsigned short fl_s[2][32];
-    __shared__ int ctl_s[2];                   // persistent form: {scene still active, tiles resident}
+    __shared__ int ctl_s[2][2];                // persistent form, by iteration parity: {scene still active, tiles resident}
+    __shared__ int carry_cen[KM][2];           // persistent form: centre / shift / SED of every component as the iteration left them
+    __shared__ double carry_sh[KM][2];
+    __shared__ float carry_sed[KM * BM];
     const int tid = threadIdx.x, lane = tid & 63, wid = uniform(tid >> 6);    // wid in an SGPR: scalar branches
     float *const morph0 = a.morph[0], *const morph1 = a.morph[1], *const sed0 = a.sed[0], *const sed1 = a.sed[1];
     const float *min_g = (c0 ? morph1 : morph0) + (size_t)s * K * HW;
@@ -129,27 +142,50 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     double pre_dy = 0, pre_dx = 0;
     if (X && (wid >> 1) < K) {                  // (the generic instance has no registers to spare: it loads late)
         const int cpre = s * K + (wid >> 1);
-        pre_cy = a.centers[2 * cpre]; pre_cx = a.centers[2 * cpre + 1];
-        pre_dy = a.shifts[2 * cpre]; pre_dx = a.shifts[2 * cpre + 1];
+        if (!(P && reentered)) {
+            pre_cy = a.centers[2 * cpre]; pre_cx = a.centers[2 * cpre + 1];
+            pre_dy = a.shifts[2 * cpre]; pre_dx = a.shifts[2 * cpre + 1];
+        }
+        if (P) {       // (read unconditionally, selected by value: a select between an LDS and a global POINTER would
+                       // turn both loads into flat loads)
+            const int lcy = carry_cen[wid >> 1][0], lcx = carry_cen[wid >> 1][1];
+            const double ldy = carry_sh[wid >> 1][0], ldx = carry_sh[wid >> 1][1];
+            if (reentered) { pre_cy = lcy; pre_cx = lcx; pre_dy = ldy; pre_dx = ldx; }
+        }
     }
     float *kcache = nullptr;
     float kc_v[3] = {0.f, 0.f, 0.f};
     unsigned kc_hdr = 0;
     if (X && a.kscache && (wid >> 1) < K) {
         kcache = a.kscache + ((size_t)(s * K + (wid >> 1)) * 2 + (wid & 1)) * SC_KSC_FLOATS;
-        kc_v[0] = kcache[lane]; kc_v[1] = kcache[64 + lane]; kc_v[2] = kcache[128 + lane];
-        kc_hdr = reinterpret_cast<const unsigned *>(kcache)[192 + (lane & 7)];
+        if (P) {                               // past the L1: this wave stored them an iteration ago
+            kc_v[0] = __builtin_nontemporal_load(kcache + lane); kc_v[1] = __builtin_nontemporal_load(kcache + 64 + lane);
+            kc_v[2] = __builtin_nontemporal_load(kcache + 128 + lane);
+            kc_hdr = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(kcache) + 192 + (lane & 7));
+        } else {
+            kc_v[0] = kcache[lane]; kc_v[1] = kcache[64 + lane]; kc_v[2] = kcache[128 + lane];
+            kc_hdr = reinterpret_cast<const unsigned *>(kcache)[192 + (lane & 7)];
+        }
     }
 
     // ---------------- phase 0: issue every global load, tiles -> LDS, Gram
     float4 mreg[GPT][KM];
+    auto load4 = [&](const float *p, bool past_l1) {
+        if (P && past_l1) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+            return make_float4(v[0], v[1], v[2], v[3]);
+        }
+        return *reinterpret_cast<const float4 *>(p);
+    };
     if (!P || !resident) {
+        // (re-entered without resident tiles -- after a NaN result, or the diagnostic switch: the planes were stored
+        // by this workgroup an iteration ago, read them past the L1)
 #pragma unroll
         for (int j = 0; j < GPT; ++j) {
             const int g = tid + j * SC_FB2;
 #pragma unroll
             for (int k = 0; k < KM; ++k)
-                mreg[j][k] = (g < ngroups && k < K) ? reinterpret_cast<const float4 *>(min_g + (size_t)k * HW)[g]
+                mreg[j][k] = (g < ngroups && k < K) ? load4(min_g + (size_t)k * HW + 4 * (size_t)g, reentered)
                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -164,10 +200,15 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
                                                : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     load_images(0);
-    for (int i = tid; i < K * B; i += SC_FB2) sed_s[(i / B) * BM + (i % B)] = sed_in[i];
+    for (int i = tid; i < K * B; i += SC_FB2) {
+        float v = 0.f;
+        if (!(P && reentered)) v = sed_in[i];
+        if (P) { const float lv = carry_sed[(i / B) * BM + (i % B)]; if (reentered) v = lv; }
+        sed_s[(i / B) * BM + (i % B)] = v;
+    }
     ks_fill_lengths(fl_s, tid, fl_req);
     if (tid < 2 * KM) (&pair_flag[0][0])[tid] = 0;
-    if (P && tid == 0) { ctl_s[0] = 1; ctl_s[1] = 1; }
+    if (P && tid == 0) { ctl_s[it_old & 1][0] = 1; ctl_s[it_old & 1][1] = 1; }
     if (P && resident) {
         // (the previous iteration's last barrier ordered its tile writes before these reads)
 #pragma unroll
@@ -426,6 +467,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
                 if (lead && lane == 0) { a.shifts[2 * c] = dy; a.shifts[2 * c + 1] = dx; }
             }
             cy = uniform(cy); cx = uniform(cx); dy = uniform(dy); dx = uniform(dx);
+            if (P && lead && lane == 0) { carry_cen[k][0] = cy; carry_cen[k][1] = cx; carry_sh[k][0] = dy; carry_sh[k][1] = dx; }
             sw = sym_window(H, W, cy, cx);
             mode = (dy != dy) ? 2 : (sw.centered ? 0 : 1);
             if (mode == 1) {
@@ -483,14 +525,19 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
 #pragma unroll
         for (int j = 0; j < GPW; ++j) {
             const int g = g0 + j * 2 * SC_WAVE;
-            lastv[j] = g < ngroups ? last4[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            lastv[j] = g < ngroups ? load4(reinterpret_cast<const float *>(last4 + g), true) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (mine && !lead) load_last();                 // the idle wave of the pair: before the barrier
     if (mine && lead) {
         int lstop = 1 << 30;                        // last sweep level computed (early exit)
         if (monotonic) wave_monotonic<float>(t, cy, cx, 0.f, &lstop);
-        if (lane == 0) { lstop_s[k] = lstop; a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx; }
+        if (lane == 0) {
+            lstop_s[k] = lstop; a.centers[2 * c] = cy; a.centers[2 * c + 1] = cx;
+            // persistent form: the final pass writes the NORMALISED values back into the tile, the peak pixel among
+            // them, while the partner wave may not have read the peak yet -- the lead hands it over with lstop
+            if (P) nmax_s[k][0] = t.m[cy * LW + cx];
+        }
         load_last();
     }
     if (mine) pair_sync(5, std::true_type{});                         // B4: sweep done, lstop published
@@ -539,7 +586,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
         // after the sweep no pixel exceeds the peak pixel (each is capped by a convex
         // combination of pixels closer to the peak) and the maps above are monotone:
         // morph.max() is the processed peak value (a NaN elsewhere: see below)
-        norm = sparse(t.m[cy * LW + cx]);
+        norm = sparse(P ? nmax_s[k][0] : t.m[cy * LW + cx]);
         if (norm < 0.f) norm = 0.f;
     }
     if (mine) {
@@ -615,6 +662,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
                 if (v < 0.f) v = 0.f;
                 v = v * norm;
                 sed_out[k * B + lane] = v;
+                if (P) carry_sed[k * BM + lane] = v;
                 const float d = sed_s[k * BM + lane] - v;
                 d2s = (double)(d * d);
                 n2s = (double)(v * v);
@@ -633,8 +681,8 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
             float4 *out4 = reinterpret_cast<float4 *>(mout_g + (size_t)k * HW);
             const float4 nan4 = make_float4(norm, norm, norm, norm);
             for (int g = g0; g < ngroups; g += 2 * SC_WAVE) out4[g] = nan4;
-            if (lead && lane < B) sed_out[k * B + lane] = norm;
-            if (P && lane == 0) ctl_s[1] = 0;       // the tile does not hold this result: reload from HBM
+            if (lead && lane < B) { sed_out[k * B + lane] = norm; if (P) carry_sed[k * BM + lane] = norm; }
+            if (P && lane == 0) ctl_s[it_old & 1][1] = 0;       // the tile does not hold this result: reload from HBM
         }
     }
     if (mine && lead && lane == 0) {
@@ -661,7 +709,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
                 if (clear) atomicAnd(&a.flags[s * K + kk], ~clear);
                 if (set) atomicOr(&a.flags[s * K + kk], set);
             }
-            if (done) { a.active[s] = 0; if (P) ctl_s[0] = 0; }
+            if (done) { a.active[s] = 0; if (P) ctl_s[it_old & 1][0] = 0; }
         }
     }
     STAMP(6);
@@ -671,7 +719,8 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
         // Hankel vectors): stores before the barrier, loads after it
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        return uniform(ctl_s[0] | (ctl_s[1] << 1));
+        // (by parity: a wave that is already in the next iteration re-arms the OTHER pair of words)
+        return uniform(ctl_s[it_old & 1][0] | (ctl_s[it_old & 1][1] << 1));
     }
     return 0;
 }
@@ -717,23 +766,21 @@ extern "C" __global__ __launch_bounds__(SC_FB2, 4) void SC_FIT2X_KERNEL(FusedArg
     int c0, it, left;
     bool resident;
     if (st >> 31) {
-        resident = (st >> 30) & 1; c0 = (int)((st >> 29) & 1); left = (int)(st & 0x1fffffffu);
+        resident = ((st >> 30) & 1) && !(n_iter & (1 << 30));       // (bit 30 of n_iter: diagnostic, tiles reloaded from HBM)
+        c0 = (int)((st >> 29) & 1); left = (int)(st & 0x1fffffffu);
         it = (int)__builtin_amdgcn_workgroup_id_z();
     } else {
         const int active_s = a.active[s];
         c0 = a.cur[s]; it = a.it[s];
         asm volatile("" ::"s"(c0), "s"(it));
         if (!active_s || n_iter <= 0) return;
-        left = n_iter < 0x1fffffff ? n_iter : 0x1fffffff; resident = false;
+        left = n_iter & 0xffffff; resident = false;
     }
-    const int r = iterate2_body<4, 5, 64, true>(a, s, c0, it, resident);
+    const int r = iterate2_body<4, 5, 64, true>(a, s, c0, it, resident, (st >> 31) != 0);
     if ((r & 1) && left > 1) {
         const unsigned nst = 0x80000000u | ((unsigned)(r >> 1) << 30) | ((unsigned)(c0 ^ 1) << 29) | (unsigned)(left - 1);
-        // every wave's stores are complete (iterate2_body waited and met at a barrier): drop the scalar cache's
-        // copies of what they overwrote (centres and shifts are re-read by scalar loads), re-create the launch
-        // registers, jump
-        asm volatile("s_dcache_inv\n\t"
-                     "s_mov_b64 exec, -1\n\t"
+        // (nothing the next iteration loads from memory through a cache was stored by this one: see iterate2_body)
+        asm volatile("s_mov_b64 exec, -1\n\t"
                      "s_mov_b64 s[0:1], %0\n\t"
                      "s_mov_b32 s2, %1\n\t"
                      "s_mov_b32 s3, %2\n\t"

@@ -48,10 +48,10 @@ extern "C" const char *scarlet_version(void) { return "scarlet_amd-hip 0.2 (gfx9
 // environment (SCARLET_<NAME>) at first use and changed afterwards only through scarlet_set_option.
 // None of them changes results beyond float32 rounding.
 enum { OPT_NO_EXACT = 0, OPT_NO_KSCACHE, OPT_FUSED_V1, OPT_NO_FUSED, OPT_FORCE_BLOCK_UPDATE, OPT_NO_HYBRID_SWEEP,
-       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_NO_GRAM_MFMA, OPT_NO_BIGK_FUSED, OPT_NO_PIPELINE, OPT_NO_PERSIST, OPT_COUNT };
+       OPT_PAD_LDS, OPT_STAMPS, OPT_PSF_HIPFFT, OPT_NO_BOX, OPT_NO_BOX2, OPT_NO_PSF3PASS, OPT_NO_SIDE_STREAM, OPT_NO_GRAM_MFMA, OPT_NO_BIGK_FUSED, OPT_NO_PIPELINE, OPT_NO_PERSIST, OPT_PERSIST_DBG, OPT_COUNT };
 static const char *const g_opt_names[OPT_COUNT] = {"NO_EXACT", "NO_KSCACHE", "FUSED_V1", "NO_FUSED", "FORCE_BLOCK_UPDATE",
                                                    "NO_HYBRID_SWEEP", "PAD_LDS", "STAMPS", "PSF_HIPFFT", "NO_BOX", "NO_BOX2",
-                                                   "NO_PSF3PASS", "NO_SIDE_STREAM", "NO_GRAM_MFMA", "NO_BIGK_FUSED", "NO_PIPELINE", "NO_PERSIST"};
+                                                   "NO_PSF3PASS", "NO_SIDE_STREAM", "NO_GRAM_MFMA", "NO_BIGK_FUSED", "NO_PIPELINE", "NO_PERSIST", "PERSIST_DBG"};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;
 static void options_init(void)
@@ -709,21 +709,28 @@ extern "C" int scarlet_profile_begin(int max_iterations)
     g_prof.cap = cap; g_prof.used = 0; g_prof.on = true;
     return SCARLET_OK;
 }
-extern "C" int scarlet_profile_end(double total_ms[SC_NCLASS], int64_t launches[SC_NCLASS])
+extern "C" int scarlet_profile_end_ex(double total_ms[SC_NCLASS], int64_t iterations[SC_NCLASS], int64_t launches[SC_NCLASS])
 {
     std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_prof.on) return set_err(SCARLET_E_ARG, "profiler not active");
+    if (!total_ms) return set_err(SCARLET_E_ARG, "null total_ms");
     g_prof.on = false;
-    for (int k = 0; k < SC_NCLASS; ++k) { total_ms[k] = 0; launches[k] = 0; }
+    for (int k = 0; k < SC_NCLASS; ++k) { total_ms[k] = 0; if (iterations) iterations[k] = 0; if (launches) launches[k] = 0; }
     for (int i = 0; i < g_prof.used; ++i) {
         HIP_TRY(hipEventSynchronize(g_prof.ev[2 * i + 1]));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
-        total_ms[g_prof.cls[i]] += ms; launches[g_prof.cls[i]] += g_prof.weight[i];
+        total_ms[g_prof.cls[i]] += ms;
+        if (iterations) iterations[g_prof.cls[i]] += g_prof.weight[i];
+        if (launches) launches[g_prof.cls[i]] += 1;
     }
     for (auto e : g_prof.ev) (void)hipEventDestroy(e);
     g_prof.ev.clear(); g_prof.cls.clear(); g_prof.weight.clear(); g_prof.cap = g_prof.used = 0;
     return SCARLET_OK;
+}
+extern "C" int scarlet_profile_end(double total_ms[SC_NCLASS], int64_t launches[SC_NCLASS])
+{
+    return scarlet_profile_end_ex(total_ms, launches, nullptr);
 }
 
 static int check_batch(const scarlet_batch *b)
@@ -1614,11 +1621,12 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream, int n_iter
         // an instance with every shape and switch folded at compile time
         const bool exact64 = b->K == 4 && b->B == 5 && b->H == 64 && b->W == 64 && !b->weights && b->weight_scalar == 1.0f && b->symmetric &&
                              b->monotonic && b->l0_thresh < 0.f && b->l1_thresh < 0.f && !opt(OPT_NO_EXACT);
-        if (exact64 && n_iter > 1 && !opt(OPT_NO_PERSIST)) {
+        if (n_iter > 0xffffff) n_iter = 0xffffff;
+        if (exact64 && (n_iter > 1 || (opt(OPT_PERSIST_DBG) & 2)) && !opt(OPT_NO_PERSIST)) {
             rc = allow_lds(k_fit2x, lds2);
             if (rc) return rc;
             prof_start(4, st, n_iter);
-            hipLaunchKernelGGL(k_fit2x, dim3(b->S), dim3(SC_FB2), lds2, st, f, n_iter);
+            hipLaunchKernelGGL(k_fit2x, dim3(b->S), dim3(SC_FB2), lds2, st, f, n_iter | ((opt(OPT_PERSIST_DBG) & 1) << 30));
             prof_stop(st);
             if (done) *done = n_iter;
         } else if (exact64) {

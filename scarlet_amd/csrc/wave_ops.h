@@ -507,16 +507,19 @@ __device__ __forceinline__ void pair_ks_gemm1_impl(const Tile &t, const SymWindo
                                                    int half, f32x4 (&T)[4][2])
 {
     // The sum over k is taken in groups of 16: in group k0 the j-th MFMA (j = 0..3) lets lane
-    // (lr, lq) supply k = k0 + 4 lq + j, so that every lane reads FOUR CONSECUTIVE floats of its X row
-    // and of the Hankel vector per group (one address, four immediate offsets) instead of one float
-    // per step, and a whole group is in flight while the previous one multiplies.
+    // (lr, lq) supply k = k0 + lq + 4 j -- every lane reads four floats of its X row and of the Hankel
+    // vector per group through one address and four immediate offsets (0, 4, 8, 12), and a whole group
+    // is in flight while the previous one multiplies.  The lane-group offset is lq (not 4 lq): with the
+    // tile stride == 2 (mod 32) the 32 lanes of a read's half-wave then hit banks 2 lr + lq, all
+    // different (4 lq collided with lr + 2: two-way conflicts on every operand read); and the k of one
+    // MFMA are consecutive, so the products are summed in ascending k.
     const float *bv = vec + 128;
     const int LW = t.LW, lane = lane_id(), lr = lane & 15, lq = lane >> 4;
     const float *rowp[NTR];                     // rows beyond the window read row h - 1 (zeroed at the end)
 #pragma unroll
     for (int tr = 0; tr < NTR; ++tr)
-        rowp[tr] = t.m + (s.y0 + min((tr << 4) + lr, g.h - 1)) * LW + s.x0 + 4 * lq;
-    const float *bp = bv + (half << 4) + lr + 4 * lq;
+        rowp[tr] = t.m + (s.y0 + min((tr << 4) + lr, g.h - 1)) * LW + s.x0 + lq;
+    const float *bp = bv + (half << 4) + lr + lq;
     struct Ops { float a[NTR][4], b[NI][4]; };
     // columns beyond the window (only in the last group: wp - w < 16) must count as zero
     auto fetch_as = [&](int k0, auto masked) {
@@ -527,13 +530,13 @@ __device__ __forceinline__ void pair_ks_gemm1_impl(const Tile &t, const SymWindo
         for (int tr = 0; tr < NTR; ++tr)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float x = rowp[tr][k0 + j];
-                o.a[tr][j] = (last && k0 + 4 * lq + j >= g.w) ? 0.f : x;
+                const float x = rowp[tr][k0 + 4 * j];
+                o.a[tr][j] = (last && k0 + lq + 4 * j >= g.w) ? 0.f : x;
             }
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o.b[i][j] = bp[k0 + (i << 5) + j];
+            for (int j = 0; j < 4; ++j) o.b[i][j] = bp[k0 + (i << 5) + 4 * j];
         return o;
     };
     auto fetch = [&](int k0) {

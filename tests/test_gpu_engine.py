@@ -181,13 +181,18 @@ def test_multi_iteration_launch_is_bit_identical_to_one_launch_per_iteration(BB)
     bit for bit, through centroid iterations (it % 5 == 0), a ragged e_rel stop, fixed factors, a host check every
     few iterations (several launches of several iterations each) and a second fit() call on the same batch."""
     from scarlet_amd import synth, _lib
-    S = 160
-    data = synth.make_batch(1400, S)
+    # 160 distinct scenes tiled to 1600: more workgroups than the 512 the chip holds, so that workgroups start beside
+    # workgroups that are in a later iteration (a first version handed centres and SEDs from one iteration to the next
+    # through global memory and read stale lines of the vector L1 in ~1 % of the scenes -- only in launches like that)
+    U, S = 160, 1600
+    data = synth.make_batch(1400, U)
+    data = {k: np.tile(v, (S // U,) + (1,) * (v.ndim - 1)) for k, v in data.items() if k in ("images", "centers")}
     fix = np.zeros((S, 4), dtype=np.uint8)
     fix[::3, 1] = 1
 
-    def run(per_iteration, e_rel, check_every, n=(23, 9), **kw):
+    def run(per_iteration, e_rel, check_every, n=(23, 9), dbg=0, **kw):
         _lib.set_option("NO_PERSIST", 1 if per_iteration else 0)
+        _lib.set_option("PERSIST_DBG", dbg)
         try:
             b = BB(data["images"], data["centers"])
             for name, arr in kw.items():
@@ -202,12 +207,20 @@ def test_multi_iteration_launch_is_bit_identical_to_one_launch_per_iteration(BB)
                                                         b.morph[0], b.morph[1], b.sed[0], b.sed[1])]
         finally:
             _lib.set_option("NO_PERSIST", 0)
+            _lib.set_option("PERSIST_DBG", 0)
 
     for e_rel, check_every, kw in ((0.0, 0, {}), (1e-3, 0, {}), (1e-3, 4, {}), (2e-3, 7, dict(fix_morph=fix)),
                                    (0.0, 10, dict(fix_sed=fix))):
         (l1, one), (l2, many) = run(True, e_rel, check_every, **kw), run(False, e_rel, check_every, **kw)
         assert l1 == l2
         for a, c in zip(one, many):
+            np.testing.assert_array_equal(a, c)
+    # PERSIST_DBG 1: every iteration after a launch's first reloads its tiles from memory instead of finding them in
+    # LDS (the path a NaN result takes); 2: launches of ONE iteration go through k_fit2x as well (check_every = 1)
+    ref = run(True, 1e-3, 0)
+    for dbg, check_every in ((1, 0), (2, 1), (3, 3)):
+        got = run(False, 1e-3, check_every, dbg=dbg)
+        for a, c in zip(ref[1], got[1]):
             np.testing.assert_array_equal(a, c)
     # a single iteration per call never takes the multi-iteration kernel; 1 + 1 + ... must equal one call of n
     (_, single), (_, many) = run(False, 0.0, 0, n=(1, 1)), run(False, 0.0, 0, n=(2, 0))

@@ -2,21 +2,9 @@
 runs in -- 256 headline scenes (5 x 64 x 64, 4 sources) x 50 iterations at e_rel = 0, and a second
 run to convergence at e_rel = 1e-3 (ragged stop, 3 .. ~150 iterations) -- GPU engine vs the CPU
 oracle started from the device's own initial state.  Tolerance: north_star's 1e-5 max-norm relative
-for sed / morph / loss history; centres, iteration counts and flags bit-exact.
-
-The algorithm tests pixel values against the threshold 0 in two places: the k-space symmetry zeroes
-its output wherever its INPUT, the stepped morphology, is <= 0 (`result[X <= 0] = 0`,
-operator.py:285-287) -- a jump: just above 0 the output is the average with the mirrored pixel -- and
-prox_plus (update.py:27-32).  A pixel whose value sits on the threshold to within float32 rounding
-can land on either side; after it switches on it differs for a few iterations before the two runs meet
-again.  Such a scene is NOT waived in prose: `straddles_threshold` re-runs it iteration by iteration on
-the GPU, in the float32 oracle and in the float64 oracle and accepts it only if, mechanically,
-  (i)   GPU and float32 oracle agree within 1e-5 on every array at every iteration before t0,
-  (ii)  at t0 they disagree about the SUPPORT of the morphology in some pixel p (one is exactly 0), and
-  (iii) the float64 trajectory's value at p at one of the two threshold tests of iteration t0 (the
-        stepped value entering the symmetry mask, or the value entering prox_plus) lies within
-        1e-5 x max|morph| of 0 -- i.e. the exact trajectory itself is undecided at the tolerance, so
-        both outcomes are admissible float32 evaluations of the reference.
+for sed / morph / loss history; centres, iteration counts and flags bit-exact.  The machinery and the
+float64-anchored treatment of the algorithm's one discontinuity live in tests/parity_common.py.
+(Both runs go through k_fit2x, the multi-iteration kernel: fit() launches ten iterations at a time.)
 """
 import multiprocessing as mp
 import os
@@ -25,34 +13,13 @@ import numpy as np
 import pytest
 
 from conftest import rel_err
+import parity_common as pc
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
-TOL = 1e-5
+TOL = pc.TOL
 S, FIRST = 256, 40000
-
-
-def _oracle_fit(args):
-    """worker (spawned, never touches the GPU): oracle fit from a given state"""
-    from oracle import pgm
-    images, sed0, morph0, cen0, sh0, iters, e_rel, dt = args
-    sc = pgm.scene_from_state(images.astype(dt), sed0.astype(dt), morph0.astype(dt), cen0, sh0)
-    pgm.fit(sc, iters, e_rel=e_rel)
-    return (np.array([s.sed for s in sc.sources]), np.array([s.morph for s in sc.sources]), np.array(sc.mse),
-            np.array([s.center for s in sc.sources]), len(sc.mse), [int(s.flags) for s in sc.sources])
-
-
-def _oracle_trace(images, sed0, morph0, cen0, sh0, iters, dt):
-    """per-iteration (morph after the iteration, morph as prox_plus saw it) of one scene"""
-    from oracle import pgm
-    sc = pgm.scene_from_state(images.astype(dt), sed0.astype(dt), morph0.astype(dt), cen0, sh0)
-    for s in sc.sources:
-        s.trace = dict(step=[], pre_plus=[])
-    post = []
-    pgm.fit(sc, iters, e_rel=0, callback=lambda scn: post.append(np.array([s.morph.copy() for s in scn.sources])))
-    pre = [(np.array([s.trace["step"][t] for s in sc.sources]), np.array([s.trace["pre_plus"][t] for s in sc.sources]))
-           for t in range(iters)]
-    return post, pre
+MAX_EXEMPT = 2          # fixed count (not a fraction of the batch); every use is printed and logged
 
 
 @pytest.fixture(scope="module")
@@ -61,92 +28,25 @@ def setup():
     scarlet_amd._lib.require_gpu()
     from oracle import build as obuild
     obuild.build()
-    from scarlet_amd import synth
-    scenes = [synth.make_scene(FIRST + i) for i in range(S)]
-    images = np.stack([s["images"] for s in scenes]); centers = np.stack([s["centers"] for s in scenes])
+    wl = pc.Workload()
+    images, centers = wl.scenes(FIRST, S)
     pool = mp.get_context("spawn").Pool(min(8, os.cpu_count() or 1))
-    yield scarlet_amd, images, centers, pool
+    yield scarlet_amd, wl, images, centers, pool
     pool.close(); pool.join()
 
 
-def gpu_fit(scarlet, images, centers, iters, e_rel, per_iteration=False):
-    b = scarlet.BlendBatch(images, centers, mse_capacity=iters + 1)
-    b.init_extended(np.ones(5) * 0.1)
-    st0 = [t.cpu().numpy() for t in (b.sed_current, b.morph_current, b.centers, b.shifts)]
-    snaps = []
-    if per_iteration:
-        for _ in range(iters):
-            b.fit(1, e_rel=e_rel)
-            snaps.append(b.morph_current.cpu().numpy().copy())
-    else:
-        b.fit(iters, e_rel=e_rel)
-    torch.cuda.synchronize()
-    out = dict(sed=b.sed_current.cpu().numpy(), morph=b.morph_current.cpu().numpy(), cen=b.centers.cpu().numpy(),
-               it=b.it.cpu().numpy(), flags=b.flags.cpu().numpy(), mse=b.mse_buf.cpu().numpy(), snaps=snaps,
-               status=b.status.cpu().numpy())
-    return st0, out
-
-
-def straddles_threshold(scarlet, images, centers, iters):
-    """the f64-anchored exemption of the module docstring for ONE scene; returns (ok, message)"""
-    st0, g = gpu_fit(scarlet, images[None], centers[None], iters, 0.0, per_iteration=True)
-    sed0, morph0, cen0, sh0 = (a[0] for a in st0)
-    o32, _ = _oracle_trace(images, sed0, morph0, cen0, sh0, iters, np.float32)
-    o64, pre64 = _oracle_trace(images, sed0, morph0, cen0, sh0, iters, np.float64)
-    for t in range(iters):
-        gm = g["snaps"][t][0]
-        mismatch = (gm == 0) != (o32[t] == 0)
-        close = rel_err(gm, o32[t]) <= TOL
-        if mismatch.any():
-            scale = np.abs(o64[t]).max()
-            near = np.minimum(np.abs(pre64[t][0][mismatch]), np.abs(pre64[t][1][mismatch]))
-            on_threshold = near <= TOL * scale
-            if on_threshold.any():
-                k, y, x = (int(v[np.argmax(on_threshold)]) for v in np.nonzero(mismatch))
-                return True, ("iteration %d, component %d pixel (%d, %d): float64 values at the threshold tests: stepped "
-                              "%.3e, before prox_plus %.3e (tolerance 1e-5 x %.3g); gpu %.3e, float32 oracle %.3e" % (
-                                  t + 1, k, y, x, pre64[t][0][k, y, x], pre64[t][1][k, y, x], scale, gm[k, y, x],
-                                  o32[t][k, y, x]))
-        if not close:
-            return False, "iteration %d: gpu and float32 oracle differ by %.2e with no pixel on the prox_plus threshold" % (
-                t + 1, rel_err(gm, o32[t]))
-    return False, "no divergence found when re-running the scene alone"
-
-
 def test_fifty_iterations_256_scenes(setup):
-    scarlet, images, centers, pool = setup
-    iters = 50
-    st0, g = gpu_fit(scarlet, images, centers, iters, 0.0)
-    ref = pool.map(_oracle_fit, [(images[i], st0[0][i], st0[1][i], st0[2][i], st0[3][i], iters, 0.0, np.float32)
-                                 for i in range(S)])
-    assert int(np.abs(g["status"]).sum()) == 0
-    assert (g["it"] == iters).all()
-    exempt = []
-    worst = dict(sed=0.0, morph=0.0, mse=0.0)
-    for i in range(S):
-        np.testing.assert_array_equal(g["cen"][i], ref[i][3])
-        e = dict(sed=rel_err(g["sed"][i], ref[i][0]), morph=rel_err(g["morph"][i], ref[i][1]),
-                 mse=rel_err(g["mse"][i][:iters], ref[i][2]))
-        if max(e.values()) <= TOL:
-            for k in worst:
-                worst[k] = max(worst[k], e[k])
-            continue
-        ok, msg = straddles_threshold(scarlet, images[i], centers[i], iters)
-        assert ok, "scene %d beyond 1e-5 (%s) and not a prox_plus straddle: %s" % (i, e, msg)
-        exempt.append((i, e, msg))
-    # the exemption is for isolated pixels, not a licence: at most 1 % of the scenes may use it
-    assert len(exempt) <= max(1, S // 100), exempt
-    print("\n50 iterations x %d scenes: worst errors %s; %d scene(s) on the prox_plus threshold: %s" % (
-        S, worst, len(exempt), exempt))
+    scarlet, wl, images, centers, pool = setup
+    pc.check_fixed_iterations(scarlet, wl, images, centers, pool, 50, MAX_EXEMPT, "headline shape, 50 iterations x 256 scenes")
 
 
 def test_converged_regime_ragged_stop(setup):
     """e_rel = 1e-3: every scene runs to ITS convergence (3 .. ~150 iterations); the iteration counts and
     the BlendFlag bits are integer outputs and must be equal, the converged factors within 1e-5."""
-    scarlet, images, centers, pool = setup
-    st0, g = gpu_fit(scarlet, images, centers, 200, 1e-3)
-    ref = pool.map(_oracle_fit, [(images[i], st0[0][i], st0[1][i], st0[2][i], st0[3][i], 200, 1e-3, np.float32)
-                                 for i in range(S)])
+    scarlet, wl, images, centers, pool = setup
+    st0, g = pc.gpu_fit(scarlet, wl, images, centers, 200, 1e-3)
+    ref = pool.map(pc.oracle_fit, [(images[i], st0[0][i], st0[1][i], st0[2][i], st0[3][i], 200, 1e-3, np.float32, wl.oracle_kwargs())
+                                   for i in range(S)])
     its = np.array([r[4] for r in ref])
     np.testing.assert_array_equal(g["it"], its)
     assert its.min() < 10 and its.max() > 100          # the run really is ragged and really converges
