@@ -307,7 +307,7 @@ def main():
     # fault injection for tests/test_dist_gloo.py (the launcher's watchdog): a rank that dies / hangs before the rendezvous
     if os.environ.get("SCARLET_BENCH_FAIL_RANK") == str(rank) and world > 1:
         raise RuntimeError("injected failure on rank %d (SCARLET_BENCH_FAIL_RANK)" % rank)
-    if os.environ.get("SCARLET_BENCH_HANG_RANK") == str(rank) and world > 1:
+    if os.environ.get("SCARLET_BENCH_HANG_RANK") in (str(rank), "all") and world > 1:
         time.sleep(3600)
     if world != args.gpus:
         print("error: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)

@@ -78,10 +78,13 @@ const char *scarlet_version(void);
 const char *scarlet_last_error(void);
 /* Diagnostic switches: NO_EXACT, NO_KSCACHE, FUSED_V1, NO_FUSED, FORCE_BLOCK_UPDATE,
  * NO_HYBRID_SWEEP, PAD_LDS, STAMPS, PSF_HIPFFT, NO_BOX, NO_BOX2, NO_PSF3PASS, NO_SIDE_STREAM,
- * NO_GRAM_MFMA, NO_BIGK_FUSED, NO_PIPELINE.  Each starts from the environment variable
- * SCARLET_<NAME>, read once at first use; afterwards only this call changes it.  Returns the
- * previous value (0 / 1) or SCARLET_E_ARG for an unknown name.  None changes results beyond
- * float32 rounding. */
+ * NO_GRAM_MFMA, NO_BIGK_FUSED, NO_PIPELINE, NO_PERSIST (one launch per iteration instead of k_fit2x),
+ * PERSIST_DBG.  Each starts from the environment variable SCARLET_<NAME>, read once at first use;
+ * afterwards only this call changes it.  Returns the previous value (0 / 1) or SCARLET_E_ARG for an
+ * unknown name.  None changes results beyond float32 rounding.
+ * PSF_HIPFFT and STAMPS decide the layout of a PSF batch's workspace: they are frozen by the first
+ * scarlet_batch_workspace_bytes / scarlet_batch_prepare_psf call of the process on a batch with a
+ * PSF; a later call that would change either returns SCARLET_E_ARG and changes nothing. */
 int scarlet_set_option(const char *name, int value);
 /* Diagnostics: with the STAMPS switch on, kernels that carry phase stamps (k_source_update_box: 16 shader-clock
  * values per component) write them into a buffer owned by the library; this copies up to `capacity` of

@@ -12,6 +12,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libscarlet_hip.so")
+if os.environ.get("SCARLET_LIB_PATH"):      # development: an A/B build of the same library (tools/ab_variants.sh)
+    LIB_PATH = os.environ["SCARLET_LIB_PATH"]
 
 
 class HipLibraryMissing(ImportError):

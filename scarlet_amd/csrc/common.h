@@ -169,6 +169,13 @@ __device__ __forceinline__ int dev_next_fast_len(int n) { return sc_nfl_table[n]
 // LDS row stride for an image of width W: == 2 (mod 32) so that the 16x4 MFMA A-operand
 // read pattern (16 rows x 2 consecutive columns per 32-lane group) is bank-conflict free.
 __host__ __device__ __forceinline__ int tile_stride(int W) { return ((W - 2 + 31) / 32) * 32 + 2; }
+// Row stride of the exact-shape fused instance (k_iterate2<4,5,64>, k_fit2x): == 4 (mod 32).  The sweep walks the
+// down / up wedges along (row - 1, column + 2): stride LW - 2, which is 0 (mod 32) for the stride above -- the eight
+// walkers of a wedge side then hit ONE bank -- and 2 for this one; the GEMM 2 epilogue (rows 4 lq + r, column lr)
+// becomes conflict-free as well (banks lr + 16 lq), and rows are 16-byte aligned.
+#ifndef SC_XS_STRIDE
+#define SC_XS_STRIDE 68
+#endif
 // LDS row stride for the GEMM scratch (B-operand reads: 2 rows x 16 columns per group)
 __host__ __device__ __forceinline__ int scratch_stride(int wp) { return ((wp + 31) / 32) * 32 + 16; }
 __host__ __device__ __forceinline__ int round16(int v) { return (v + 15) & ~15; }

@@ -96,7 +96,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     static_assert(1 + KM * BM <= 32 && 4 * SC_NW2 == 32, "the partial sums are combined by 32 rows of 16 lanes");
     constexpr bool X = XS > 0;
     extern __shared__ __align__(16) float lds[];
-    const int K = X ? KM : a.K, B = X ? BM : a.B, H = X ? XS : a.H, W = X ? XS : a.W, HW = H * W, LW = tile_stride(W);
+    const int K = X ? KM : a.K, B = X ? BM : a.B, H = X ? XS : a.H, W = X ? XS : a.W, HW = H * W, LW = X ? SC_XS_STRIDE : tile_stride(W);
     const int tile_floats = H * LW;
     const bool symmetric = X ? true : a.symmetric != 0, monotonic = X ? true : a.monotonic != 0;
     float *tiles = lds;
@@ -131,6 +131,16 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     const float *wgt = (!X && a.weights) ? a.weights + (size_t)s * B * HW : nullptr;
 #define STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)s * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
+    // (diagnostics: the constant 100 MHz counter beside the shader clock of stamps 0 / 6 gives the clock the chip holds)
+    if (a.stamps && tid == 0) a.stamps[(size_t)s * 16 + 7] = (long long)__builtin_amdgcn_s_memrealtime();
+#ifdef SC_STAMP_PERIOD      // (diagnostic build: the start of the last two iterations, by parity, in slots 8 / 9 of the second half)
+    if (P && a.stamps && tid == 0) a.stamps[(size_t)a.S * 16 + (size_t)s * 2 + (it_new & 1)] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    if (P && a.stamps && tid == 0 && !reentered) {     // launch-level diagnostics: when and where this workgroup started
+        a.stamps[(size_t)s * 16 + 14] = (long long)__builtin_amdgcn_s_memrealtime();
+        a.stamps[(size_t)s * 16 + 15] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11))        // HW_ID
+                                        | ((long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);   // XCC_ID
+    }
     const unsigned fl_req = ks_request_lengths(tid);
     // The Hankel vectors of the k-space symmetry depend on (H, W, centre, shift) only; the shift moves
     // every fifth iteration and the centre rarely, so each wave keeps its half of the vectors of the
@@ -503,9 +513,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     f32x4 T[4][2];
     if (mine && mode == 1) {
         if (rank1) pair_ks_z(kg, vec + 256, zv);
-        STAMP(14);
         pair_ks_gemm1<true>(t, sw, kg, vec, half, T);
-        STAMP(15);
     }
     if (mine) pair_sync(3, std::false_type{});                         // B2: every read of X is done
     STAMP(13);
@@ -691,33 +699,38 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     }
     STAMP(5);
 
-    // ---------------- phase 3: Blend._check_convergence + bookkeeping (blend.py:141-184)
-    if (tid == 0) {
-        a.it[s] = it_new;
-        a.cur[s] = 1 - c0;
-        if (it_new > 1) {
-            bool done = true;
-            for (int kk = 0; kk < K; ++kk) {
-                // the two convergence bits are rewritten whatever they were, the other bits stay: posted
-                // atomics instead of load - modify - store (a load here would put an HBM round trip at the
-                // very end of the workgroup, with its LDS and registers still held)
-                int set = 0;
-                const double d2 = conv_m[kk][0][0] + conv_m[kk][1][0], n2 = conv_m[kk][0][1] + conv_m[kk][1][1];
-                if (!(n2 == n2 && conv_s[kk][0] <= a.e_rel2 * conv_s[kk][1])) { set |= SCARLET_FLAG_SED_NOT_CONVERGED; done = false; }
-                if (!(d2 <= a.e_rel2 * n2)) { set |= SCARLET_FLAG_MORPH_NOT_CONVERGED; done = false; }
-                const int clear = (SCARLET_FLAG_SED_NOT_CONVERGED | SCARLET_FLAG_MORPH_NOT_CONVERGED) & ~set;
-                if (clear) atomicAnd(&a.flags[s * K + kk], ~clear);
-                if (set) atomicOr(&a.flags[s * K + kk], set);
-            }
+    // ---------------- phase 3: Blend._check_convergence + bookkeeping (blend.py:141-184): lane k of wave 0 tests
+    // component k (one lane for all of them was ~2.6k cycles at the end of every scene's chain)
+    if (wid == 0) {
+        bool pending = false;
+        if (lane < K && it_new > 1) {
+            // the two convergence bits are rewritten whatever they were, the other bits stay: posted
+            // atomics instead of load - modify - store (a load here would put an HBM round trip at the
+            // very end of the workgroup, with its LDS and registers still held)
+            const int kk = lane;
+            int set = 0;
+            const double d2 = conv_m[kk][0][0] + conv_m[kk][1][0], n2 = conv_m[kk][0][1] + conv_m[kk][1][1];
+            if (!(n2 == n2 && conv_s[kk][0] <= a.e_rel2 * conv_s[kk][1])) set |= SCARLET_FLAG_SED_NOT_CONVERGED;
+            if (!(d2 <= a.e_rel2 * n2)) set |= SCARLET_FLAG_MORPH_NOT_CONVERGED;
+            const int clear = (SCARLET_FLAG_SED_NOT_CONVERGED | SCARLET_FLAG_MORPH_NOT_CONVERGED) & ~set;
+            if (clear) atomicAnd(&a.flags[s * K + kk], ~clear);
+            if (set) atomicOr(&a.flags[s * K + kk], set);
+            pending = set != 0;
+        }
+        const bool done = it_new > 1 && __builtin_amdgcn_ballot_w64(pending) == 0;
+        if (lane == 0) {
+            a.it[s] = it_new;
+            a.cur[s] = 1 - c0;
             if (done) { a.active[s] = 0; if (P) ctl_s[it_old & 1][0] = 0; }
         }
     }
     STAMP(6);
+    if (a.stamps && tid == 0) a.stamps[(size_t)s * 16 + 11] = (long long)__builtin_amdgcn_s_memrealtime();
 #undef STAMP
     if (P) {
-        // the next iteration reads back what this one stored (previous morphology, centres, shifts, cached
-        // Hankel vectors): stores before the barrier, loads after it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (no wait for this iteration's global stores here: what the next iteration needs of them is in LDS, the
+        // previous morphology is re-read tens of thousands of cycles from now and the cached Hankel vectors by the
+        // wave that stored them.  The wait cost ~14k cycles per iteration -- the drain of the final pass's 64 KB.)
         __syncthreads();
         // (by parity: a wave that is already in the next iteration re-arms the OTHER pair of words)
         return uniform(ctl_s[it_old & 1][0] | (ctl_s[it_old & 1][1] << 1));
@@ -754,17 +767,35 @@ __global__ __launch_bounds__(SC_FB2, 4) void k_iterate2(FusedArgs a)
 // iterations remain, its last instruction is a jump back to its own first instruction with the registers a fresh
 // wave starts with re-created: kernel-argument pointer, workgroup id and work-item id, plus the loop state in the
 // two registers a 1-D grid leaves at zero (workgroup id y = {re-entered, tiles resident, buffer index, iterations
-// left}, workgroup id z = iteration count).  LDS is untouched by the jump.  The register assignment this relies
+// left}, workgroup id z = iteration count).  The same jump, with those two registers at zero and another workgroup
+// id x, starts the NEXT SCENE of the launch's queue on this workgroup.  LDS is untouched by the jump.  The register assignment this relies
 // on (user SGPRs = kernel-argument pointer only, workgroup ids x / y / z in s2 / s3 / s4, packed work-item id in
 // v0, no private segment) is the HSA ABI for the kernel descriptor the compiler emits; tools/check_reentry_abi.py
 // verifies those descriptor fields on every build and the library refuses to launch this kernel otherwise.
 #define SC_FIT2X_KERNEL k_fit2x
-extern "C" __global__ __launch_bounds__(SC_FB2, 4) void SC_FIT2X_KERNEL(FusedArgs a, int n_iter)
+// re-creates the registers a fresh wave of this kernel starts with and jumps to the kernel's first instruction
+// (never returns); `scene` / `state` / `it` arrive as workgroup ids x / y / z
+#define SC_FIT2X_REENTER(scene, state, it)                                                                     \
+    asm volatile("s_mov_b64 exec, -1\n\t"                                                                      \
+                 "s_mov_b64 s[0:1], %0\n\t"                                                                    \
+                 "s_mov_b32 s2, %1\n\t"                                                                        \
+                 "s_mov_b32 s3, %2\n\t"                                                                        \
+                 "s_mov_b32 s4, %3\n\t"                                                                        \
+                 "v_mov_b32 v0, %4\n\t"                                                                        \
+                 "s_getpc_b64 s[6:7]\n\t"                                                                      \
+                 "s_add_u32 s6, s6, k_fit2x@rel32@lo+4\n\t"                                                    \
+                 "s_addc_u32 s7, s7, k_fit2x@rel32@hi+12\n\t"                                                  \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                    \
+                 "s_setpc_b64 s[6:7]"                                                                          \
+                 :                                                                                             \
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "s"(scene), "s"(state), "s"(it), "v"((int)threadIdx.x) \
+                 : "s0", "s1", "s2", "s3", "s4", "s6", "s7", "v0", "scc", "memory")
+extern "C" __global__ __launch_bounds__(SC_FB2, 4) void SC_FIT2X_KERNEL(FusedArgs a, int n_iter, int *queue, int n_workgroups)
 {
-    const int s = blockIdx.x;
-    const unsigned st = (unsigned)__builtin_amdgcn_workgroup_id_y();     // 0 at launch (1-D grid)
-    int c0, it, left;
-    bool resident;
+    const int s = blockIdx.x;                                            // the scene (workgroup id x, rewritten on re-entry)
+    const unsigned st = (unsigned)__builtin_amdgcn_workgroup_id_y();     // 0 at launch (1-D grid) and for a new scene
+    int c0 = 0, it = 0, left = 0;
+    bool resident = false, run = true;
     if (st >> 31) {
         resident = ((st >> 30) & 1) && !(n_iter & (1 << 30));       // (bit 30 of n_iter: diagnostic, tiles reloaded from HBM)
         c0 = (int)((st >> 29) & 1); left = (int)(st & 0x1fffffffu);
@@ -773,26 +804,33 @@ extern "C" __global__ __launch_bounds__(SC_FB2, 4) void SC_FIT2X_KERNEL(FusedArg
         const int active_s = a.active[s];
         c0 = a.cur[s]; it = a.it[s];
         asm volatile("" ::"s"(c0), "s"(it));
-        if (!active_s || n_iter <= 0) return;
-        left = n_iter & 0xffffff; resident = false;
+        left = n_iter & 0xffffff;
+        run = active_s && left > 0;
     }
-    const int r = iterate2_body<4, 5, 64, true>(a, s, c0, it, resident, (st >> 31) != 0);
-    if ((r & 1) && left > 1) {
-        const unsigned nst = 0x80000000u | ((unsigned)(r >> 1) << 30) | ((unsigned)(c0 ^ 1) << 29) | (unsigned)(left - 1);
-        // (nothing the next iteration loads from memory through a cache was stored by this one: see iterate2_body)
-        asm volatile("s_mov_b64 exec, -1\n\t"
-                     "s_mov_b64 s[0:1], %0\n\t"
-                     "s_mov_b32 s2, %1\n\t"
-                     "s_mov_b32 s3, %2\n\t"
-                     "s_mov_b32 s4, %3\n\t"
-                     "v_mov_b32 v0, %4\n\t"
-                     "s_getpc_b64 s[6:7]\n\t"
-                     "s_add_u32 s6, s6, k_fit2x@rel32@lo+4\n\t"
-                     "s_addc_u32 s7, s7, k_fit2x@rel32@hi+12\n\t"
-                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-                     "s_setpc_b64 s[6:7]"
-                     :
-                     : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "s"(s), "s"(nst), "s"(it + 1), "v"((int)threadIdx.x)
-                     : "s0", "s1", "s2", "s3", "s4", "s6", "s7", "v0", "scc", "memory");
+    if (run) {
+        const int r = iterate2_body<4, 5, 64, true>(a, s, c0, it, resident, (st >> 31) != 0);
+        if ((r & 1) && left > 1) {
+            const unsigned nst = 0x80000000u | ((unsigned)(r >> 1) << 30) | ((unsigned)(c0 ^ 1) << 29) | (unsigned)(left - 1);
+            if (!(r & 2) || (n_iter & (1 << 30))) {
+                // the next iteration reloads its tiles from the planes this one has just stored (a NaN result, or the
+                // diagnostic switch): every wave's stores first
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // (nothing the next iteration loads from memory through a cache was stored by this one: see iterate2_body)
+            SC_FIT2X_REENTER(s, nst, it + 1);
+        }
     }
+    // This scene is finished for this launch (iterations done, converged, or inactive from the start): take the next
+    // one from the launch's queue.  The grid holds only as many workgroups as the chip keeps resident (n_workgroups);
+    // scenes beyond the first n_workgroups are handed out by a counter.  Leaving that to the hardware dispatcher
+    // -- one workgroup per scene -- left a CU's second slot empty for ~70 us (median 34, p90 206) after every workgroup
+    // of 1.6 ms: the dispatcher deals workgroups to CUs in a fixed order and waits for THAT CU (measured with
+    // tools/occupancy.py: 1.84 resident workgroups per CU instead of 2).
+    __shared__ int next_s;
+    if (threadIdx.x == 0) next_s = queue ? atomicAdd(queue, 1) + n_workgroups : a.S;
+    __syncthreads();
+    const int nx = uniform(next_s);
+    __syncthreads();                                                    // (next_s is rewritten by whoever gets here first next time)
+    if (nx < a.S) SC_FIT2X_REENTER(nx, 0u, 0);
 }

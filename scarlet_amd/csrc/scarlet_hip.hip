@@ -69,12 +69,22 @@ static void options_init(void)
     });
 }
 static inline int opt(int which) { options_init(); return g_opt[which].load(std::memory_order_relaxed); }
+// PSF_HIPFFT and STAMPS decide the LAYOUT of a PSF batch's workspace (psf_layout): they are read when a workspace is
+// sized and again by every later call on that batch, so a change in between would move regions under a live batch
+// (K-hat and tables read from the wrong offsets, writes past the allocation).  The first layout computed in the
+// process therefore FREEZES the two switches: scarlet_set_option then refuses a different value (SCARLET_E_ARG).
+static std::atomic<bool> g_layout_frozen{false};
 extern "C" int scarlet_set_option(const char *name, int value)
 {
     options_init();
     if (!name) return set_err(SCARLET_E_ARG, "null option name");
     for (int i = 0; i < OPT_COUNT; ++i)
-        if (!strcmp(name, g_opt_names[i])) return g_opt[i].exchange(value) != 0 ? 1 : 0;
+        if (!strcmp(name, g_opt_names[i])) {
+            if ((i == OPT_PSF_HIPFFT || i == OPT_STAMPS) && g_layout_frozen.load() && (g_opt[i].load() != 0) != (value != 0))
+                return set_err(SCARLET_E_ARG, "PSF_HIPFFT / STAMPS fix the workspace layout of PSF batches: they cannot change "
+                                              "after the first PSF workspace of the process was sized");
+            return g_opt[i].exchange(value) != 0 ? 1 : 0;
+        }
     return set_err(SCARLET_E_ARG, "unknown option");
 }
 
@@ -141,7 +151,7 @@ static long long *debug_stamps(size_t count)
 extern "C" int64_t scarlet_debug_stamps(int64_t *out, int64_t capacity)
 {
     std::lock_guard<std::mutex> lock(g_dbg_mu);
-    if (!g_dbg_stamps || !out) return 0;
+    if (!g_dbg_stamps || !out || capacity <= 0) return 0;
     const int64_t n = capacity < (int64_t)g_dbg_count ? capacity : (int64_t)g_dbg_count;
     if (hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(out, g_dbg_stamps, n * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
@@ -877,6 +887,7 @@ static bool psf_use_lds(const scarlet_batch *b, FftPlan *p) { return psf_lds_pos
 struct PsfLayout { int64_t loss, real, spec, khat, lds_khat, lds_tables, stamps, total; };
 static PsfLayout psf_layout(const scarlet_batch *b)
 {
+    g_layout_frozen.store(true);                      // (see scarlet_set_option)
     const PsfGeom g = psf_geom(b->H, b->W, b->psf_h, b->psf_w);
     const int64_t planes = (int64_t)b->S * b->B;
     const int64_t nk = b->diff_kernel_per_scene ? planes : (int64_t)b->B;
@@ -1560,6 +1571,27 @@ extern "C" int scarlet_check_convergence(scarlet_batch *b, double e_rel, void *s
     return SCARLET_OK;
 }
 
+// workgroups of k_fit2x the current device keeps resident at once (occupancy query x compute units), per device
+static int fit2x_resident_workgroups(size_t lds, int *out)
+{
+    static std::mutex mu;
+    static int cached[64] = {0};
+    static size_t cached_lds[64] = {0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return set_err(SCARLET_E_HIP, "device index out of range");
+    std::lock_guard<std::mutex> lock(mu);
+    if (!cached[dev] || cached_lds[dev] != lds) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fit2x, SC_FB2, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (per_cu < 1) per_cu = 1;
+        cached[dev] = per_cu * cus; cached_lds[dev] = lds;
+    }
+    *out = cached[dev];
+    return SCARLET_OK;
+}
+
 // ---- fused one-kernel iteration (fused.h)
 static size_t fused_lds_bytes(const scarlet_batch *b)
 {
@@ -1621,19 +1653,28 @@ static int launch_fused(scarlet_batch *b, double e_rel, void *stream, int n_iter
         // an instance with every shape and switch folded at compile time
         const bool exact64 = b->K == 4 && b->B == 5 && b->H == 64 && b->W == 64 && !b->weights && b->weight_scalar == 1.0f && b->symmetric &&
                              b->monotonic && b->l0_thresh < 0.f && b->l1_thresh < 0.f && !opt(OPT_NO_EXACT);
+        // (the exact-shape instances use their own tile stride, common.h SC_XS_STRIDE)
+        const size_t lds2x = sizeof(float) * ((size_t)4 * 64 * SC_XS_STRIDE + (size_t)4 * SC_PAIR_VEC_FLOATS) + (size_t)opt(OPT_PAD_LDS);
         if (n_iter > 0xffffff) n_iter = 0xffffff;
         if (exact64 && (n_iter > 1 || (opt(OPT_PERSIST_DBG) & 2)) && !opt(OPT_NO_PERSIST)) {
-            rc = allow_lds(k_fit2x, lds2);
+            rc = allow_lds(k_fit2x, lds2x);
             if (rc) return rc;
+            // as many workgroups as the chip keeps resident; the scenes beyond them come from the launch's queue
+            // (a counter in the workspace, zeroed on the stream in front of the launch)
+            int n_wg = 0;
+            if ((rc = fit2x_resident_workgroups(lds2x, &n_wg))) return rc;
+            if (n_wg > b->S || (opt(OPT_PERSIST_DBG) & 4)) n_wg = b->S;            // (4: diagnostic, one workgroup per scene)
+            int *queue = (int *)((char *)b->workspace + base_workspace_bytes(b) - 128);
+            HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int), st));
             prof_start(4, st, n_iter);
-            hipLaunchKernelGGL(k_fit2x, dim3(b->S), dim3(SC_FB2), lds2, st, f, n_iter | ((opt(OPT_PERSIST_DBG) & 1) << 30));
+            hipLaunchKernelGGL(k_fit2x, dim3(n_wg), dim3(SC_FB2), lds2x, st, f, n_iter | ((opt(OPT_PERSIST_DBG) & 1) << 30), queue, n_wg);
             prof_stop(st);
             if (done) *done = n_iter;
         } else if (exact64) {
-            rc = allow_lds(k_iterate2<4, 5, 64>, lds2);
+            rc = allow_lds(k_iterate2<4, 5, 64>, lds2x);
             if (rc) return rc;
             prof_start(4, st);
-            hipLaunchKernelGGL((k_iterate2<4, 5, 64>), dim3(b->S), dim3(SC_FB2), lds2, st, f);
+            hipLaunchKernelGGL((k_iterate2<4, 5, 64>), dim3(b->S), dim3(SC_FB2), lds2x, st, f);
             prof_stop(st);
         } else
             LAUNCH_ITERATE2(5);

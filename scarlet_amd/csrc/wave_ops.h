@@ -228,6 +228,9 @@ __device__ __forceinline__ Walker<T> make_walker(bool xmajor, int e, int H, int 
 // 16 lanes per wedge (two sides of the axis x eight values b = 2 j + parity) cover all four
 // wedges in ONE trip.  (Even, so that the two-trip loop resumes on an odd level.)
 #define SC_COMPACT_LAST 46
+#ifndef SC_SWEEP_MASKED
+#define SC_SWEEP_MASKED 0            // measured (tools/ab_variants.sh): -1.5 % at tile stride 66, +0.8 % at stride 68
+#endif
 template <typename T>
 __device__ __forceinline__ Walker<T> make_compact_walker(int e, int H, int W, int LW, int cy, int cx, int lane)
 {
@@ -288,10 +291,27 @@ __device__ inline void wave_monotonic(const TileT<T> &t, int cy, int cx, T thres
     auto pin = [&](const Prep &q) {
         asm volatile("" ::"v"(q.p), "v"(q.p1), "v"(q.p2), "v"(q.p3), "v"(q.p4), "v"(q.c1), "v"(q.c2), "v"(q.c3));
     };
+    // Bank conflicts of these gathers (tools/sweep_banks.py simulates them over random centres): every lane issues its
+    // five reads, idle ones at whatever address their walker state gives (values discarded).  At a tile stride == 2
+    // (mod 32) that is 11.6 LDS cycles per 64-lane read on average instead of 2 -- the down / up wedges advance by
+    // (row - 1, column + 2) per lane, stride - 2 == 0 (mod 32): eight walkers on ONE bank -- and the sweep's reads were
+    // more than half of the kernel's LDS-active cycles.  Two remedies, measured on the headline kernel: a stride == 4
+    // (mod 32) (common.h SC_XS_STRIDE: 5.9 cycles per read, -2.6 % kernel time) and masking the idle lanes
+    // (SC_SWEEP_MASKED: 5.5 / 3.9 cycles at stride 66 / 68; -1.5 % at 66, but +0.8 % at 68: the masking's own
+    // instructions).  The value registers persist across levels, so a masked lane keeps (and ignores) what it last read.
+    Vals vals_reg = {};
     auto load = [&](const Prep &q, const Walker<T> &w) {
+#if SC_SWEEP_MASKED
+        if (q.act) {
+            vals_reg.x0 = *(LdsT *)q.p; vals_reg.x2 = *(LdsT *)q.p2; vals_reg.x1 = *(LdsT *)q.p1;
+            vals_reg.x3 = *(LdsT *)q.p3; vals_reg.x4 = *(LdsT *)q.p4;
+        }
+        return vals_reg;
+#else
         Vals v;
         v.x0 = *(LdsT *)q.p; v.x2 = *(LdsT *)q.p2; v.x1 = *(LdsT *)q.p1; v.x3 = *(LdsT *)q.p3; v.x4 = *(LdsT *)q.p4;
         return v;
+#endif
     };
     auto finish = [&](const Prep &q, const Vals &v, const Walker<T> &w) {
         const T inv = fast_rcp(q.c1 + q.c2 + q.c3 + w.c4);

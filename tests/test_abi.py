@@ -85,6 +85,31 @@ def test_error_paths_return_codes_without_touching_memory():
     assert _lib.lib.scarlet_batch_pipelines(None) == 0
 
 
+def test_layout_switches_freeze_with_the_first_psf_workspace():
+    """PSF_HIPFFT and STAMPS decide where the regions of a PSF batch's workspace lie and are read again by
+    every later call on the batch; once a PSF workspace has been sized they can no longer change (SCARLET_E_ARG).
+    In a child process: the freeze is process-wide."""
+    import sys
+    code = """
+import ctypes, sys
+sys.path.insert(0, %r)
+from scarlet_amd import _lib
+assert _lib.set_option("PSF_HIPFFT", 1) == 0 and _lib.set_option("PSF_HIPFFT", 0) == 1      # free before
+b = _lib.ScarletBatch()
+b.S, b.K, b.B, b.H, b.W, b.psf_h, b.psf_w = 4, 2, 3, 32, 32, 11, 11
+b.diff_kernel = 1                                                                        # (only tested against NULL)
+assert _lib.lib.scarlet_batch_workspace_bytes(ctypes.byref(b)) > 0
+assert _lib.lib.scarlet_set_option(b"PSF_HIPFFT", 1) == _lib.E_ARG and b"layout" in _lib.lib.scarlet_last_error()
+assert _lib.lib.scarlet_set_option(b"STAMPS", 1) == _lib.E_ARG
+assert _lib.lib.scarlet_set_option(b"PSF_HIPFFT", 0) == 0                                  # the value it has: fine
+assert _lib.lib.scarlet_set_option(b"NO_BOX", 1) == 0                                      # other switches stay free
+assert _lib.lib.scarlet_debug_stamps(None, -5) == 0
+print("ok")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode == 0 and b"ok" in out.stdout, out.stderr.decode()[-1500:]
+
+
 def test_asan_error_paths():
     """`make asan`: the host code of the library under AddressSanitizer + LeakSanitizer, driven through the
     argument-error and HIP-error exits of every entry point that allocates (tests/native/abi_asan_check.c).

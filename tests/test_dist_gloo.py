@@ -79,16 +79,10 @@ def test_launcher_ends_the_run_when_a_rank_dies_before_the_rendezvous():
 
 
 def test_launcher_time_limit():
-    """every rank hangs: the launcher's own limit ends the run and says which rank was still running"""
+    """ranks that never finish: the launcher's own limit ends the run and says which rank was still running"""
     import subprocess
-    env = dict(os.environ, SCARLET_BENCH_HANG_RANK="0", SCARLET_BENCH_LIMIT_S="3")
+    env = dict(os.environ, SCARLET_BENCH_HANG_RANK="all")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    # rank 1 would fail for lack of a GPU here; make it hang as well by pointing both hooks at their ranks
-    env["SCARLET_BENCH_HANG_RANK"] = "0"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], env=dict(env, WORLD_SIZE="1"),
-                       capture_output=True, timeout=120) if False else None
-    env2 = dict(env)
-    p = subprocess.run([sys.executable, "-c",
-                        "import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.self_launch(1, ['--gpus', '1'], limit_s=3))" % ROOT],
-                       env=dict(env2, SCARLET_BENCH_HANG_ALWAYS="1"), capture_output=True, timeout=120)
-    assert p.returncode != 0 and "time limit" in p.stderr.decode()
+    code = "import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.self_launch(2, ['--gpus', '2', '--scenes', '4', '--no-cpu'], limit_s=3))" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=120)
+    assert p.returncode != 0 and "time limit" in p.stderr.decode(), p.stderr.decode()[-500:]

@@ -13,5 +13,13 @@ if os.environ.get('PMC_NOSYM'): kw['symmetric'] = False
 if os.environ.get('PMC_NOMONO'): kw['monotonic'] = False
 b = BlendBatch(imgs, cen, **kw)
 b.init_extended(np.ones(5) * .1)
-b.fit(5, e_rel=0, check_every=0)
+# PMC_WARM iterations as single-iteration launches (k_iterate2: another kernel name), then ONE launch of PMC_ITERS
+# iterations (k_fit2x) in the steady state -- the first four iterations of a fit run the flip symmetry, not the GEMMs
+from scarlet_amd import _lib
+warm, iters = int(os.environ.get("PMC_WARM", "10")), int(os.environ.get("PMC_ITERS", "10"))
+if warm:
+    _lib.set_option("NO_PERSIST", 1)
+    b.fit(warm, e_rel=0, check_every=0)
+    _lib.set_option("NO_PERSIST", int(os.environ.get("SCARLET_NO_PERSIST", "0") or 0))
+b.fit(iters, e_rel=0, check_every=0)
 torch.cuda.synchronize()

@@ -36,3 +36,8 @@ if st[:, 12].any():
     if st[:, 11].any(): print("P2 wave0 own tail:", (st[:, 11] - st[:, 10]).mean().round(0))
 print("phase cycles mean:", dt.mean(axis=0).round(0), " total", (st[:, 6] - st[:, 0]).mean())
 print("phase cycles p90 :", np.percentile(dt, 90, axis=0).round(0))
+if st[:, 7].any() and st[:, 11].any():
+    cyc, ticks = (st[:, 6] - st[:, 0]).astype(float), (st[:, 11] - st[:, 7]).astype(float)
+    ok = ticks > 0
+    print("in-kernel clock (shader cycles per 100 MHz tick x 100 MHz): median %.0f MHz, p10 %.0f, p90 %.0f" % (
+        np.median(cyc[ok] / ticks[ok]) * 100, np.percentile(cyc[ok] / ticks[ok], 10) * 100, np.percentile(cyc[ok] / ticks[ok], 90) * 100))
