@@ -211,9 +211,13 @@ struct FftPlan {
     int stagger_wgs;                    // k_psf_conv: number of workgroups of the first generation (CUs of the device)
     int tab_off;                        // LDS offset (float2) of the tables: behind the plane and the image staging area
     int dma_image;                      // k_psf_conv: the image is staged in LDS by LDS-DMA (rows >= H + the space behind the plane)
-    const float2 *tables;               // device: twy[Fy] = w_Fy^j, twm[M] = w_M^j, twx[M/2 + 1] = w_Fx^k, then posx[M] (uint16)
+    const float2 *tables;               // device: twy[Fy] = w_Fy^j, twm[M] = w_M^j, twx[M/2 + 1] = w_Fx^k, then posx[M] (uint16),
+                                        // then the column pairs in position order: twp[NP] and pair[NP] = {ra, rb, cb, 0} (uint16 x 4)
 };
-__host__ __device__ inline int fft_table_float2s(int Fy, int M) { return Fy + M + (M / 2 + 1) + (M + 3) / 4; }
+// NP = M/2 + 1 pairs (k, M - k) of spectrum columns.  The fused column passes visit them in the order of their
+// POSITION in the permuted row (ra ascending; then rb = const - ra descends): consecutive lanes read consecutive
+// float2, where the order of k walked the row at stride R2x (two-way bank conflicts on every paired read).
+__host__ __device__ inline int fft_table_float2s(int Fy, int M) { return Fy + M + (M / 2 + 1) + (M + 3) / 4 + 2 * (M / 2 + 1); }
 // LDS of the transform kernels: the plane [Fy][RS], then the tables.  k_psf_conv additionally stages the image
 // plane (H x W floats) from row H on -- rows >= H are idle between the render's column stage and the adjoint's,
 // which is when the residual needs the image -- so its tables sit behind max(plane, H rows + image).
@@ -289,10 +293,12 @@ __device__ __forceinline__ void fft_lines_inv(float2 *A, int nlines, int ls, int
     fft_pass<true>(R1, A, nlines, ls, R2, es, R2 * es, tw, false, lf);          // A^-1
 }
 
+struct FftPair { unsigned short ra, rb, cb, pad; };    // read positions of the pair, write position of its second member
 struct FftLds {
     float2 *A;                  // [Fy][RS]
-    const float2 *twy, *twm, *twx;
+    const float2 *twy, *twm, *twx, *twp;
     const unsigned short *posx;
+    const FftPair *pair;
 };
 __device__ __forceinline__ FftLds fft_lds_setup(float2 *lds, const FftPlan &p)
 {
@@ -303,6 +309,8 @@ __device__ __forceinline__ FftLds fft_lds_setup(float2 *lds, const FftPlan &p)
     for (int i = threadIdx.x; i < nt; i += SC_FFT_NT) t[i] = p.tables[i];
     l.twy = t; l.twm = t + p.Fy; l.twx = l.twm + p.M;
     l.posx = (const unsigned short *)(l.twx + (p.M / 2 + 1));
+    l.twp = l.twx + (p.M / 2 + 1) + (p.M + 3) / 4;
+    l.pair = (const FftPair *)(l.twp + (p.M / 2 + 1));
     return l;
 }
 
@@ -472,11 +480,10 @@ __device__ __forceinline__ void cols_A_untangle(const FftLds &l, const FftPlan &
     const int total = NP * R2;
     const float rcp = 1.0f / (float)NP;
     for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
-        const int n2 = fast_div(u, rcp), k = u - n2 * NP;
-        const bool first = (k == 0), mid = (2 * k == M);
-        const int ra = l.posx[k], rb = (first || mid) ? ra : l.posx[M - k];
-        const int cb = first ? M : rb;
-        const float2 w = l.twx[k];
+        const int n2 = fast_div(u, rcp), i = u - n2 * NP;
+        const FftPair pr = l.pair[i];
+        const int ra = pr.ra, rb = pr.rb, cb = pr.cb;
+        const float2 w = l.twp[i];
         float2 xa[R], xb[R];
 #pragma unroll
         for (int n1 = 0; n1 < R; ++n1) {
@@ -537,11 +544,11 @@ __device__ __forceinline__ void cols_Ainv_tangle(const FftLds &l, const FftPlan 
     const int total = NP * R2;
     const float rcp = 1.0f / (float)NP;
     for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
-        const int n2 = fast_div(u, rcp), k = u - n2 * NP;
-        const bool first = (k == 0), mid = (2 * k == M);
-        const int ra = l.posx[k], rb = (first || mid) ? ra : l.posx[M - k];
-        const int cb = first ? M : rb;
-        const float2 w = l.twx[k];
+        const int n2 = fast_div(u, rcp), i = u - n2 * NP;
+        const FftPair pr = l.pair[i];
+        const int ra = pr.ra, rb = pr.rb, cb = pr.cb;
+        const bool first = cb == M;                              // (k = 0: its second member lives in the extra slot M)
+        const float2 w = l.twp[i];
         float2 xa[R], xb[R];
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) {

@@ -119,6 +119,9 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     __shared__ int carry_cen[KM][2];           // persistent form: centre / shift / SED of every component as the iteration left them
     __shared__ double carry_sh[KM][2];
     __shared__ float carry_sed[KM * BM];
+    // persistent form: rows [lo, hi] outside which factor buffer 0 / 1 of component k holds exact zeros -- what this
+    // launch's final passes wrote there (everything beyond the sweep's cut); [0, H - 1] until a buffer has been written
+    __shared__ short rowrange_s[KM][2][2];
     const int tid = threadIdx.x, lane = tid & 63, wid = uniform(tid >> 6);    // wid in an SGPR: scalar branches
     float *const morph0 = a.morph[0], *const morph1 = a.morph[1], *const sed0 = a.sed[0], *const sed1 = a.sed[1];
     const float *min_g = (c0 ? morph1 : morph0) + (size_t)s * K * HW;
@@ -219,6 +222,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     ks_fill_lengths(fl_s, tid, fl_req);
     if (tid < 2 * KM) (&pair_flag[0][0])[tid] = 0;
     if (P && tid == 0) { ctl_s[it_old & 1][0] = 1; ctl_s[it_old & 1][1] = 1; }
+    if (P && !reentered && tid < KM * 4) (&rowrange_s[0][0][0])[tid] = (short)((tid & 1) ? H - 1 : 0);
     if (P && resident) {
         // (the previous iteration's last barrier ordered its tile writes before these reads)
 #pragma unroll
@@ -527,13 +531,24 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     const int y0 = g0 / gpr, x0 = g0 - y0 * gpr;
     // the previous morphology (buffer c0) for the convergence sums: requested now, all 16 B/lane
     // loads in flight together, so that the HBM latency is paid under the sweep
+    // persistent form: rows of the previous morphology (buffer c0) and of the plane this iteration overwrites (buffer
+    // 1 - c0) that can hold anything but zeros; read here, before the pair's last synchronisation (the lead rewrites
+    // the second range after its final pass)
+    int rl_lo = 0, rl_hi = H - 1, ro_lo = 0, ro_hi = H - 1;
+    if (P && mine) {
+        rl_lo = uniform((int)rowrange_s[k][c0][0]); rl_hi = uniform((int)rowrange_s[k][c0][1]);
+        ro_lo = uniform((int)rowrange_s[k][1 - c0][0]); ro_hi = uniform((int)rowrange_s[k][1 - c0][1]);
+    }
     float4 lastv[GPW];
     auto load_last = [&]() {
         const float4 *last4 = reinterpret_cast<const float4 *>(min_g + (size_t)k * HW);
 #pragma unroll
         for (int j = 0; j < GPW; ++j) {
             const int g = g0 + j * 2 * SC_WAVE;
-            lastv[j] = g < ngroups ? load4(reinterpret_cast<const float *>(last4 + g), true) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // (persistent form: the previous morphology is zero outside its recorded rows -- not loaded)
+            const int row = y0 + j * dyq;              // (dxq == 0 for the exact shape: a lane keeps its column group)
+            const bool want = g < ngroups && (!P || (row >= rl_lo && row <= rl_hi));
+            lastv[j] = want ? load4(reinterpret_cast<const float *>(last4 + g), true) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (mine && !lead) load_last();                 // the idle wave of the pair: before the barrier
@@ -606,13 +621,26 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
         f32x2 d2p = {0.f, 0.f}, n2p = {0.f, 0.f};        // <= 32 float terms per lane, then f64 across lanes
         const f32x2 rn2 = {rnorm, rnorm}, nm2 = {norm, norm};
         // CUT: zero beyond the sweep's last level; GEN: thresholds and/or an irregular norm
+        // persistent form: only the rows where the new morphology (inside the sweep's cut), the previous one or the
+        // old content of the output plane can be non-zero; everywhere else all three are exact zeros: nothing to
+        // store, nothing to add to the sums
+        int u_lo = 0, u_hi = H - 1;
+        if (P && cut && regular && l0 < 0.f && l1 < 0.f) {
+            const int rt = lstop >> 1;                                 // rows beyond cy +- lstop / 2 are cut whole
+            u_lo = min(min(rl_lo, ro_lo), max(cy - rt, 0)); u_hi = max(max(rl_hi, ro_hi), min(cy + rt, H - 1));
+        }
         auto final_pass = [&](auto cut_c, auto gen_c) {
             constexpr bool CUT = decltype(cut_c)::value, GEN = decltype(gen_c)::value;
             int y = y0, xq = x0;
 #pragma unroll
             for (int j = 0; j < GPW; ++j) {
                 const int g = g0 + j * 2 * SC_WAVE;
-                if (g < ngroups) {
+                // (the wave's four rows of this trip: wave-uniform test, exact shape only)
+                const int yw = uniform(y0 + j * dyq) & ~3;
+                const bool skip = P && X && (yw + 3 < u_lo || yw > u_hi);
+                // (the tile itself must read zero there for the next iteration's phase 0: it holds stepped values)
+                if (g < ngroups && skip) lds_store4(t.m + y * LW + (xq << 2), make_float4(0.f, 0.f, 0.f, 0.f));
+                if (g < ngroups && !skip) {
                     const float4 v4 = lds_load4(t.m + y * LW + (xq << 2));
                     const float4 l = lastv[j];
                     float v[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -663,6 +691,11 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
         }
         const double d2 = wave_sum((double)(d2p.x + d2p.y)), n2 = wave_sum((double)(n2p.x + n2p.y));
         if (lane == 0) { conv_m[k][half][0] = d2; conv_m[k][half][1] = n2; }
+        if (P && lead && lane == 0) {                   // the rows of the plane just written that are not all zero
+            const bool known = cut && regular && l0 < 0.f && l1 < 0.f;
+            rowrange_s[k][1 - c0][0] = (short)(known ? max(cy - (lstop >> 1), 0) : 0);
+            rowrange_s[k][1 - c0][1] = (short)(known ? min(cy + (lstop >> 1), H - 1) : H - 1);
+        }
         if (lead) {
             double d2s = 0, n2s = 0;
             if (lane < B) {
@@ -690,7 +723,10 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
             const float4 nan4 = make_float4(norm, norm, norm, norm);
             for (int g = g0; g < ngroups; g += 2 * SC_WAVE) out4[g] = nan4;
             if (lead && lane < B) { sed_out[k * B + lane] = norm; if (P) carry_sed[k * BM + lane] = norm; }
-            if (P && lane == 0) ctl_s[it_old & 1][1] = 0;       // the tile does not hold this result: reload from HBM
+            if (P && lane == 0) {
+                ctl_s[it_old & 1][1] = 0;                        // the tile does not hold this result: reload from HBM
+                rowrange_s[k][1 - c0][0] = 0; rowrange_s[k][1 - c0][1] = (short)(H - 1);
+            }
         }
     }
     if (mine && lead && lane == 0) {

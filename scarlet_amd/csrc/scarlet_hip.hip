@@ -11,6 +11,7 @@
 #include <mutex>
 #include <tuple>
 #include <vector>
+#include <algorithm>
 #include <hipfft/hipfft.h>
 
 #include "common.h"
@@ -850,6 +851,9 @@ static bool fft_make_plan(int H, int W, int Py, int Px, FftPlan *p)
     if (!fft_choose(Fy_min, false, &Fy, &r1y, &r2y)) return false;
     if (!fft_choose((Fx_min + 1) / 2, true, &M, &r1x, &r2x)) return false;
     p->H = H; p->W = W; p->Fy = Fy; p->Fx = 2 * M; p->M = M; p->RS = M + 1;
+    // (A row stride == R2x (mod 32) -- 85 instead of 81 for BASELINE config 3 -- was tried so that the bank windows of
+    // consecutive lines tile in the row passes: SQ_LDS_BANK_CONFLICT rose from 0.76e8 to 1.10e8 per launch and the
+    // iteration took 8.19 ms instead of 8.00; the plane keeps its dense stride.  profiles/r03_notes.md)
     p->R1y = r1y; p->R2y = r2y; p->R1x = r1x; p->R2x = r2x;
     p->Py = Py; p->Px = Px; p->oky = oky; p->okx = okx;
     p->scale = (float)(1.0 / ((double)M * (double)Fy));
@@ -870,6 +874,21 @@ static void fft_fill_tables(const FftPlan &p, std::vector<float2> &t)
     for (int k = 0; k <= p.M / 2; ++k) twx[k] = make_float2((float)cos(tau * k / p.Fx), (float)-sin(tau * k / p.Fx));
     unsigned short *posx = (unsigned short *)(twx + (p.M / 2 + 1));
     for (int k = 0; k < p.M; ++k) posx[k] = (unsigned short)(p.R2x * (k % p.R1x) + k / p.R1x);
+    // the column pairs (k, M - k), k = 0 .. M/2, in the order of their first member's position (fftconv.h FftPair)
+    const int NP = p.M / 2 + 1;
+    float2 *twp = twx + NP + (p.M + 3) / 4;
+    FftPair *pair = (FftPair *)(twp + NP);
+    std::vector<int> order(NP);
+    for (int k = 0; k < NP; ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return posx[a] < posx[b]; });
+    for (int i = 0; i < NP; ++i) {
+        const int k = order[i];
+        const bool first = k == 0, mid = 2 * k == p.M;
+        const int ra = posx[k], rb = (first || mid) ? ra : posx[p.M - k];
+        pair[i].ra = (unsigned short)ra; pair[i].rb = (unsigned short)rb;
+        pair[i].cb = (unsigned short)(first ? p.M : rb); pair[i].pad = 0;
+        twp[i] = twx[k];
+    }
 }
 static bool psf_lds_possible(const scarlet_batch *b, FftPlan *p)
 {

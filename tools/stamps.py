@@ -18,6 +18,10 @@ b.workspace[:S * 16 * 8].zero_()
 b.fit(int(os.environ.get("STAMP_ITERS", "1")), e_rel=0, check_every=0)
 torch.cuda.synchronize()
 st = b.workspace[:S * 16 * 8].view(torch.int64).view(S, 16).cpu().numpy()
+if int(os.environ.get("STAMP_ITERS", "1")) > 1 and S > 2048:
+    # multi-iteration launch: the last iteration of the scenes that finish while the chip is still full (the last
+    # ~1000 scenes of the queue finish beside emptying CUs and run faster)
+    st = st[:S - 1024]
 dt = np.diff(st[:, :7], axis=1)
 if st[:, 10].any():
     print("P2 wave0: pre-sym %d  sym %d  sweep %d  tail %d" % ((st[:, 8] - st[:, 4]).mean(), (st[:, 9] - st[:, 8]).mean(),
