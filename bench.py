@@ -289,6 +289,8 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: `scenes` in total, generated on rank 0 and scattered over RCCL")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--clock-warmup-ms", type=float, default=60.0,
+                    help="untimed device clock warm-up on a scratch copy of the batch before the W warmup steps (0: none)")
     ap.add_argument("--no-other", action="store_true",
                     help="headline workload only (the default single-GPU c2 run also times c3 and c5 in child processes)")
     ap.add_argument("--cpu-scenes", type=int, default=None, help="oracle scenes per host process")
@@ -396,15 +398,38 @@ def main():
                monotonic=not args.no_monotonic, l0_thresh=cfg["l0"])
     if cfg["psf"]:
         bkw["centroid_weight"] = model_psf.astype(np.float32)
-    batch = BlendBatch(images, centers, **bkw)
-    sed_scale = None
+    sed_scale = diff = None
     if cfg["psf"]:
         from scarlet_amd import fft as fftmod
-        diff = fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
-                                 fftmod.Fourier(model_psf[None].astype(np.float32))).image
-        batch.set_diff_kernel(np.asarray(diff, dtype=np.float32))
+        diff = np.asarray(fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                            fftmod.Fourier(model_psf[None].astype(np.float32))).image, dtype=np.float32)
         sed_scale = (model_psf.max() / obs_psfs.max(axis=(1, 2))).astype(np.float32)
-    batch.init_extended(np.ones(B, dtype=np.float32) * 0.1, sed_scale=sed_scale)
+
+    def make_batch():
+        bb = BlendBatch(images, centers, **bkw)
+        if diff is not None:
+            bb.set_diff_kernel(diff)
+        bb.init_extended(np.ones(B, dtype=np.float32) * 0.1, sed_scale=sed_scale)
+        return bb
+
+    # Device clock warm-up, NOT part of the W warmup steps and not timed: the GPU has idled through the host-side legs
+    # (scene generation, CPU baseline) and W = 5 iterations are ~3 ms -- the timed region would start at idle clocks
+    # (measured: 0.66 - 0.68 ms per step after 5 warmup iterations, 0.64 after 50, 0.63 in a 200-step run).  The same
+    # iterations run on a SCRATCH copy of the batch for >= clock_warmup_ms, the copy is freed, then the contract's
+    # W + K steps run on the real batch.
+    clock_warm = {"iterations": 0, "ms": 0.0}
+    if args.clock_warmup_ms > 0:
+        scratch = make_batch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < args.clock_warmup_ms and clock_warm["iterations"] < 400:
+            scratch.fit(10, e_rel=0, check_every=0)
+            torch.cuda.synchronize()
+            clock_warm["iterations"] += 10
+        clock_warm["ms"] = (time.perf_counter() - t0) * 1e3
+        del scratch
+        torch.cuda.empty_cache()
+    batch = make_batch()
     torch.cuda.synchronize()
     if args.warmup > 0:
         batch.fit(args.warmup, e_rel=0, check_every=0)
@@ -510,6 +535,8 @@ def main():
                    "batch_iterations_per_s": args.steps / elapsed,
                    "active_scenes_after_timed_region": n_active, "scenes_with_status": status_bad,
                    "mean_loss_first_last": [float(mse[:, 0].mean()), float(mse[:, -1].mean())],
+                   "device_clock_warmup": dict(clock_warm, on="a scratch copy of the batch, freed before the W warmup steps; "
+                                                               "untimed, not counted in `warmup`"),
                    "host_scene_generation_s": t_gen,
                    "scatter_s": t_scatter, "gather_s": t_gather,
                    "end_to_end_scene_iterations_per_s": total_scene_iters / (elapsed + t_scatter + t_gather)},
