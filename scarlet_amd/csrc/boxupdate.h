@@ -478,8 +478,11 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
 
 // NB: bands of 16 window rows the kernel is built for (8: frames up to 128 rows, 16: up to 256).
 // The small box: one workgroup per component, four per CU.
+#ifndef SC_UB_WAVES
+#define SC_UB_WAVES 4            // workgroups of the small-box kernel per CU (tools/ab_box.sh builds variants with -DSC_UB_WAVES=n)
+#endif
 template <int NB, int XS>
-__global__ __launch_bounds__(SC_BLOCK, 4) void k_source_update_box(UpdateArgs a, int *fallback, int *list, int *count, long long *stamps_all)
+__global__ __launch_bounds__(SC_BLOCK, SC_UB_WAVES) void k_source_update_box(UpdateArgs a, int *fallback, int *list, int *count, long long *stamps_all)
 {
     ub_component<NB, 31, XS>(a, blockIdx.x, fallback, list, count, stamps_all);
 }

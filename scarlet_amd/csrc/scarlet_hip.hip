@@ -1130,7 +1130,16 @@ static int side_stream(SideStream **out)
     if (t_n == 16) { *out = nullptr; return SCARLET_OK; }   // (more devices than that in one thread: no second stream)
     SideStream &n = t_side[t_n];
     HIP_TRY(hipStreamCreateWithFlags(&n.st, hipStreamNonBlocking));
-    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreateWithFlags(&n.ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) {
+        const hipError_t e = hipEventCreateWithFlags(&n.ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) {                                  // nothing of a half-built entry survives
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(n.ev[j]);
+            (void)hipStreamDestroy(n.st);
+            n.st = nullptr;
+            snprintf(g_err, sizeof(g_err), "HIP error: %s (side stream events)", hipGetErrorString(e));
+            return SCARLET_E_HIP;
+        }
+    }
     n.device = dev;
     ++t_n;
     *out = &n;
@@ -1746,9 +1755,10 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
                 return code;
             };
             for (int i = 0; i < max_iter; ++i) {
+#define HIP_TRY_BAIL(expr) do { if ((expr) != hipSuccess) { set_err(SCARLET_E_HIP, "HIP call failed in the two-pipeline loop: " #expr); return bail(SCARLET_E_HIP); } } while (0)
                 if (!forked) {
                     HIP_TRY(hipEventRecord(side->ev[0], st));
-                    HIP_TRY(hipStreamWaitEvent(side->st, side->ev[0], 0));
+                    HIP_TRY_BAIL(hipStreamWaitEvent(side->st, side->ev[0], 0));
                     forked = true;
                 }
                 for (int h = 0; h < 2; ++h) {
@@ -1762,8 +1772,8 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
                 ++launched;
                 const bool check = check_every > 0 && (i + 1) % check_every == 0 && i + 1 < max_iter;
                 if (check || i + 1 == max_iter) {
-                    HIP_TRY(hipEventRecord(side->ev[1], side->st));
-                    HIP_TRY(hipStreamWaitEvent(st, side->ev[1], 0));
+                    HIP_TRY_BAIL(hipEventRecord(side->ev[1], side->st));
+                    HIP_TRY_BAIL(hipStreamWaitEvent(st, side->ev[1], 0));
                     forked = false;
                 }
                 if (check) {
@@ -1774,6 +1784,7 @@ extern "C" int scarlet_fit(scarlet_batch *b, int max_iter, double e_rel, int app
                     if (h_count == 0) break;
                 }
             }
+#undef HIP_TRY_BAIL
             return launched;
         }
     }
