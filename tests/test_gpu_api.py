@@ -738,3 +738,45 @@ def test_iteration_with_second_stream_survives_graph_capture(scarlet, case):
     np.testing.assert_array_equal(npy(b.morph_current), npy(ref.morph_current))
     np.testing.assert_array_equal(npy(b.sed_current), npy(ref.sed_current))
     np.testing.assert_array_equal(npy(b.mse_buf)[:, :5], npy(ref.mse_buf)[:, :5])
+
+
+def test_multi_iteration_launch_survives_graph_capture(scarlet):
+    """scarlet_fit on the headline shape is ONE k_fit2x launch behind a memset of its scene-queue counter: both must be
+    capturable.  A 3-iteration fit captured once and replayed three times after an eager 3-iteration warm-up, against 12
+    eager iterations: bit-identical (700 scenes: more than the 512 workgroups of the launch, so the queue is used)."""
+    import ctypes
+    from scarlet_amd import synth, _lib
+    U, S = 70, 700
+    d = synth.make_batch(2600, U)
+    images, centers = np.tile(d["images"], (S // U, 1, 1, 1)), np.tile(d["centers"], (S // U, 1, 1))
+
+    def make():
+        b = scarlet.BlendBatch(images, centers)
+        b.init_extended(np.ones(5) * 0.1)
+        return b
+
+    ref = make()
+    ref.fit(12, e_rel=0, check_every=0)
+    torch.cuda.synchronize()
+    b = make()
+    b._ensure_mse_capacity(16)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sp = ctypes.c_void_p(st.cuda_stream)
+
+        def three_iterations():
+            assert _lib.lib.scarlet_fit(ctypes.byref(b._c), 3, 0.0, 0, 0, sp) == 3
+        three_iterations()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            three_iterations()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+    np.testing.assert_array_equal(npy(b.it), npy(ref.it))
+    np.testing.assert_array_equal(npy(b.morph_current), npy(ref.morph_current))
+    np.testing.assert_array_equal(npy(b.sed_current), npy(ref.sed_current))
+    np.testing.assert_array_equal(npy(b.mse_buf)[:, :12], npy(ref.mse_buf)[:, :12])
+    np.testing.assert_array_equal(npy(b.flags), npy(ref.flags))
