@@ -98,6 +98,19 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
     extern __shared__ __align__(16) float lds[];
     const int K = X ? KM : a.K, B = X ? BM : a.B, H = X ? XS : a.H, W = X ? XS : a.W, HW = H * W, LW = X ? SC_XS_STRIDE : tile_stride(W);
     const int tile_floats = H * LW;
+    // float4 access to the tiles: one 16-byte LDS instruction where the rows are 16-byte aligned (the exact-shape
+    // stride 68), two 8-byte ones otherwise
+#ifndef SC_TILE_B128
+#define SC_TILE_B128 1
+#endif
+    auto tl4 = [](const float *p) {
+        if constexpr (X && SC_TILE_B128 && (SC_XS_STRIDE % 4) == 0) return *reinterpret_cast<const float4 *>(p);
+        else return lds_load4(p);
+    };
+    auto ts4 = [](float *p, float4 v) {
+        if constexpr (X && SC_TILE_B128 && (SC_XS_STRIDE % 4) == 0) *reinterpret_cast<float4 *>(p) = v;
+        else lds_store4(p, v);
+    };
     const bool symmetric = X ? true : a.symmetric != 0, monotonic = X ? true : a.monotonic != 0;
     float *tiles = lds;
     float *vecs = lds + (size_t)K * tile_floats;
@@ -231,7 +244,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
             const int y = g / gpr, x = (g - y * gpr) << 2;
 #pragma unroll
             for (int k = 0; k < KM; ++k)
-                mreg[j][k] = (g < ngroups && k < K) ? lds_load4(tiles + k * tile_floats + y * LW + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+                mreg[j][k] = (g < ngroups && k < K) ? tl4(tiles + k * tile_floats + y * LW + x) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     const bool small_side = (K <= B);          // nonzero spectrum of A^T A == that of A A^T
@@ -249,7 +262,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
                 const int y = g / gpr, x = (g - y * gpr) << 2;
 #pragma unroll
                 for (int k = 0; k < KM; ++k)
-                    if (k < K && !(P && resident)) lds_store4(tiles + k * tile_floats + y * LW + x, mreg[j][k]);
+                    if (k < K && !(P && resident)) ts4(tiles + k * tile_floats + y * LW + x, mreg[j][k]);
                 int gi = 0;
 #pragma unroll
                 for (int k = 0; k < KM; ++k)
@@ -351,7 +364,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
 #pragma unroll
                 for (int k = 0; k < KM; ++k) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < K) v = lds_load4(tiles + k * tile_floats + y * LW + x);
+                    if (k < K) v = tl4(tiles + k * tile_floats + y * LW + x);
                     m2[k][0] = (f32x2){v.x, v.y}; m2[k][1] = (f32x2){v.z, v.w};
                     gm2[k][0] = (f32x2){0.f, 0.f}; gm2[k][1] = gm2[k][0];
                 }
@@ -383,7 +396,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
                 for (int k = 0; k < KM; ++k)
                     if (k < K && !fixm[k]) {
                         const f32x2 o0 = m2[k][0] - step_morph * gm2[k][0], o1 = m2[k][1] - step_morph * gm2[k][1];
-                        lds_store4(tiles + k * tile_floats + y * LW + x, make_float4(o0.x, o0.y, o1.x, o1.y));
+                        ts4(tiles + k * tile_floats + y * LW + x, make_float4(o0.x, o0.y, o1.x, o1.y));
                     }
             }
         }
@@ -639,9 +652,9 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
                 const int yw = uniform(y0 + j * dyq) & ~3;
                 const bool skip = P && X && (yw + 3 < u_lo || yw > u_hi);
                 // (the tile itself must read zero there for the next iteration's phase 0: it holds stepped values)
-                if (g < ngroups && skip) lds_store4(t.m + y * LW + (xq << 2), make_float4(0.f, 0.f, 0.f, 0.f));
+                if (g < ngroups && skip) ts4(t.m + y * LW + (xq << 2), make_float4(0.f, 0.f, 0.f, 0.f));
                 if (g < ngroups && !skip) {
-                    const float4 v4 = lds_load4(t.m + y * LW + (xq << 2));
+                    const float4 v4 = tl4(t.m + y * LW + (xq << 2));
                     const float4 l = lastv[j];
                     float v[4] = {v4.x, v4.y, v4.z, v4.w};
                     // level(x, y) = 2 max(ax, ay) + min(ax, ay) <= lstop  <=>  ax <= axmax(ay): one
@@ -673,7 +686,7 @@ __device__ __forceinline__ int iterate2_body(const FusedArgs &a, const int s, co
                     }
                     const float4 o4 = make_float4(o01.x, o01.y, o23.x, o23.y);
                     out4[g] = o4;
-                    if (P) lds_store4(t.m + y * LW + (xq << 2), o4);     // the next iteration's phase 0 reads the tile
+                    if (P) ts4(t.m + y * LW + (xq << 2), o4);     // the next iteration's phase 0 reads the tile
                     const f32x2 e01 = (f32x2){l.x, l.y} - o01, e23 = (f32x2){l.z, l.w} - o23;
                     d2p += e01 * e01; d2p += e23 * e23;
                     n2p += o01 * o01; n2p += o23 * o23;
