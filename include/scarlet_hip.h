@@ -319,6 +319,9 @@ int scarlet_check_convergence(scarlet_batch *b, double e_rel, void *stream);
  * iterations and start recording; end: synchronise, return per kernel class
  * {0 k_grad, 1 k_step, 2 k_source_update, 3 k_converge, 4 k_iterate (fused), 5-7 unused}
  * the summed milliseconds and launch counts, and stop recording. */
+/* diagnostics (STAMPS switch on): byte offset inside b->workspace of the convolution kernel's phase stamps
+ * ([S][B][32] int64 shader-clock values, written by every k_psf_conv launch), or -1 */
+int64_t scarlet_debug_psf_stamps_offset(const scarlet_batch *b);
 int scarlet_profile_begin(int max_iterations);
 int scarlet_profile_end(double total_ms[8], int64_t launches[8]);
 /* the same with both counts: `iterations` = iterations covered by the class's launches (what

@@ -236,13 +236,13 @@ __device__ __forceinline__ int fast_div(int u, float rcp_d) { return (int)(((flo
 
 // one pass over `nlines` independent 1-D transforms: item (line, j) loads v[q] = A[line*ls + j*joff + q*qs],
 // q < R, transforms, multiplies output k by (conj) tw[j k] when use_tw, and stores back in place.
-template <int R, bool INV>
+template <int R, bool INV, int NT = SC_FFT_NT>
 __device__ __forceinline__ void fft_items(float2 *A, int nlines, int ls, int J, int joff, int qs, const float2 *tw,
                                           bool use_tw, bool line_fastest)
 {
     const int total = nlines * J;
     const float rcp = 1.0f / (float)(line_fastest ? nlines : J);
-    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+    for (int u = threadIdx.x; u < total; u += NT) {
         int line, j;
         if (line_fastest) { j = fast_div(u, rcp); line = u - j * nlines; }
         else { line = fast_div(u, rcp); j = u - line * J; }
@@ -263,12 +263,12 @@ __device__ __forceinline__ void fft_items(float2 *A, int nlines, int ls, int J, 
     }
 }
 
-template <bool INV>
+template <bool INV, int NT = SC_FFT_NT>
 __device__ __forceinline__ void fft_pass(int R, float2 *A, int nlines, int ls, int J, int joff, int qs, const float2 *tw,
                                          bool use_tw, bool line_fastest)
 {
     switch (R) {
-#define SC_FFT_CASE(R_) case R_: fft_items<R_, INV>(A, nlines, ls, J, joff, qs, tw, use_tw, line_fastest); break;
+#define SC_FFT_CASE(R_) case R_: fft_items<R_, INV, NT>(A, nlines, ls, J, joff, qs, tw, use_tw, line_fastest); break;
     SC_FFT_CASE(4) SC_FFT_CASE(5) SC_FFT_CASE(6) SC_FFT_CASE(7) SC_FFT_CASE(8) SC_FFT_CASE(9) SC_FFT_CASE(10)
     SC_FFT_CASE(12) SC_FFT_CASE(14) SC_FFT_CASE(15) SC_FFT_CASE(16)
 #undef SC_FFT_CASE
@@ -300,13 +300,14 @@ struct FftLds {
     const unsigned short *posx;
     const FftPair *pair;
 };
+template <int NT = SC_FFT_NT>
 __device__ __forceinline__ FftLds fft_lds_setup(float2 *lds, const FftPlan &p)
 {
     FftLds l;
     l.A = lds;
     float2 *t = lds + p.tab_off;
     const int nt = fft_table_float2s(p.Fy, p.M);
-    for (int i = threadIdx.x; i < nt; i += SC_FFT_NT) t[i] = p.tables[i];
+    for (int i = threadIdx.x; i < nt; i += NT) t[i] = p.tables[i];
     l.twy = t; l.twm = t + p.Fy; l.twx = l.twm + p.M;
     l.posx = (const unsigned short *)(l.twx + (p.M / 2 + 1));
     l.twp = l.twx + (p.M / 2 + 1) + (p.M + 3) / 4;
@@ -473,13 +474,13 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_fft_convolve(const float *in, Fft
 //   rows_Ainv_store     : last inverse row pass of the adjoint -> G in global memory
 // 14 passes (= barriers) per plane and iteration instead of 25.  Rows >= H of the plane are never
 // read from LDS (they are zero by construction: predicated), so nothing has to clear them.
-template <int R>
+template <int R, int NT = SC_FFT_NT>
 __device__ __forceinline__ void cols_A_untangle(const FftLds &l, const FftPlan &p)
 {
     const int M = p.M, NP = M / 2 + 1, R2 = p.R2y, RS = p.RS, H = p.H;
     const int total = NP * R2;
     const float rcp = 1.0f / (float)NP;
-    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+    for (int u = threadIdx.x; u < total; u += NT) {
         const int n2 = fast_div(u, rcp), i = u - n2 * NP;
         const FftPair pr = l.pair[i];
         const int ra = pr.ra, rb = pr.rb, cb = pr.cb;
@@ -510,13 +511,13 @@ __device__ __forceinline__ void cols_A_untangle(const FftLds &l, const FftPlan &
     __syncthreads();
 }
 
-template <int R, bool CONJ>
+template <int R, bool CONJ, int NT = SC_FFT_NT>
 __device__ __forceinline__ void cols_B_mul_Binv(const FftLds &l, const FftPlan &p, const float2 *khat)
 {
     const int cols = p.M + 1, J = p.R1y, RS = p.RS;
     const int total = cols * J;
     const float rcp = 1.0f / (float)cols;
-    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+    for (int u = threadIdx.x; u < total; u += NT) {
         const int k1 = fast_div(u, rcp), c = u - k1 * cols;
         float2 *q = l.A + (R * k1) * RS + c;
         const float2 *kq = khat + (R * k1) * cols + c;
@@ -537,13 +538,13 @@ __device__ __forceinline__ void cols_B_mul_Binv(const FftLds &l, const FftPlan &
     __syncthreads();
 }
 
-template <int R>
+template <int R, int NT = SC_FFT_NT>
 __device__ __forceinline__ void cols_Ainv_tangle(const FftLds &l, const FftPlan &p)
 {
     const int M = p.M, NP = M / 2 + 1, R2 = p.R2y, RS = p.RS, H = p.H;
     const int total = NP * R2;
     const float rcp = 1.0f / (float)NP;
-    for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
+    for (int u = threadIdx.x; u < total; u += NT) {
         const int n2 = fast_div(u, rcp), i = u - n2 * NP;
         const FftPair pr = l.pair[i];
         const int ra = pr.ra, rb = pr.rb, cb = pr.cb;
@@ -582,12 +583,13 @@ __device__ __forceinline__ void cols_Ainv_tangle(const FftLds &l, const FftPlan 
 // or spills).  16 B per lane, wave-uniform LDS base + lane * 16: the staged image is lane-linear [H][W] floats.
 // Requested after the render's column stage, landed by the barrier that ends the next row pass.
 #define SC_FFT_PF 16                     // model-plane pairs a thread holds in registers at kernel start
+template <int NT = SC_FFT_NT>
 __device__ __forceinline__ void fft_dma_image(const FftLds &l, const FftPlan &p, const float *img)
 {
     const int nchunks = (p.H * p.W) >> 2;             // 16-byte pieces (H W % 4 == 0: checked on the host)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *stage = reinterpret_cast<float *>(l.A + p.H * p.RS);
-    for (int c0 = wave * 64; c0 < nchunks; c0 += SC_FFT_NT) {
+    for (int c0 = wave * 64; c0 < nchunks; c0 += NT) {
         if (c0 + lane < nchunks)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (size_t)(c0 + lane) * 4),
                                              (__attribute__((address_space(3))) void *)(stage + (size_t)c0 * 4), 16, 0, 0);
@@ -595,13 +597,14 @@ __device__ __forceinline__ void fft_dma_image(const FftLds &l, const FftPlan &p,
 }
 // d = w (render - image), loss, w d back into the plane (columns >= W/2 of the rows stay zero from the build);
 // `pf` holds the first SC_FFT_PF * SC_FFT_NT pairs, the rest (larger frames) is read here
+template <int NT = SC_FFT_NT>
 __device__ __forceinline__ void fft_residual(const FftLds &l, const FftPlan &p, const float2 *img,
                                              const float2 *wgt, float wscalar, double &loss)
 {
     const int Wh = p.W >> 1, npairs = p.H * Wh;
     const float rcp = 1.0f / (float)Wh;
     const float2 *stage = l.A + p.H * p.RS;           // the image as the LDS-DMA left it: [H][W/2] pairs, lane-linear
-    for (int u = threadIdx.x; u < npairs; u += SC_FFT_NT) {
+    for (int u = threadIdx.x; u < npairs; u += NT) {
         const int y = fast_div(u, rcp), n = u - y * Wh;
         float2 *q = l.A + y * p.RS + n;
         const float2 r = *q, im = p.dma_image ? stage[u] : img[u];
@@ -614,7 +617,7 @@ __device__ __forceinline__ void fft_residual(const FftLds &l, const FftPlan &p, 
     const int pad = p.M - Wh;
     if (pad > 0) {
         const float rcp2 = 1.0f / (float)pad;
-        for (int u = threadIdx.x; u < p.H * pad; u += SC_FFT_NT) {
+        for (int u = threadIdx.x; u < p.H * pad; u += NT) {
             const int y = fast_div(u, rcp2), n = Wh + (u - y * pad);
             l.A[y * p.RS + n] = make_float2(0.f, 0.f);
         }
@@ -634,24 +637,24 @@ __device__ __forceinline__ void fft_residual(const FftLds &l, const FftPlan &p, 
 
 // one convolution up to (not including) the last inverse row pass: rows fwd, columns (fused), rows B^-1
 #define FFT_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-template <bool CONJ, typename AfterColumns>
+template <bool CONJ, int NT = SC_FFT_NT, typename AfterColumns>
 __device__ __forceinline__ void fft_conv_core(const FftLds &l, const FftPlan &p, const float2 *khat, long long *stamps,
                                               AfterColumns &&after_columns)
 {
-    fft_pass<false>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, true, false);                         // rows A
+    fft_pass<false, NT>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, true, false);                     // rows A
     FFT_STAMP(0);
-    fft_pass<false>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, false, false);                        // rows B
+    fft_pass<false, NT>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, false, false);                    // rows B
     FFT_STAMP(1);
-    SC_FFT_DISPATCH(p.R1y, (cols_A_untangle<RR>(l, p)))
+    SC_FFT_DISPATCH(p.R1y, (cols_A_untangle<RR, NT>(l, p)))
     FFT_STAMP(2);
-    SC_FFT_DISPATCH(p.R2y, (cols_B_mul_Binv<RR, CONJ>(l, p, khat)))
+    SC_FFT_DISPATCH(p.R2y, (cols_B_mul_Binv<RR, CONJ, NT>(l, p, khat)))
     FFT_STAMP(3);
-    SC_FFT_DISPATCH(p.R1y, (cols_Ainv_tangle<RR>(l, p)))
+    SC_FFT_DISPATCH(p.R1y, (cols_Ainv_tangle<RR, NT>(l, p)))
     FFT_STAMP(4);
     after_columns();                     // the low-register-pressure row passes follow: global loads go here
-    fft_pass<true>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, true, false);                          // rows B^-1
+    fft_pass<true, NT>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, true, false);                      // rows B^-1
     FFT_STAMP(5);
-    fft_pass<true>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, false, false);                         // rows A^-1
+    fft_pass<true, NT>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, false, false);                     // rows A^-1
     FFT_STAMP(6);
 }
 
@@ -660,8 +663,19 @@ __device__ __forceinline__ void fft_conv_core(const FftLds &l, const FftPlan &p,
 // one streaming read of the K morphologies per SCENE -- building the plane here costs K plane reads per
 // BAND through this CU's load path, a third of the kernel when measured) and the gradient planes on exit.
 // grid: one workgroup per (scene, band); consecutive scenes go to consecutive XCDs.
-__global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, float *G, long long *stamps_all)
+// XP: the exact-shape instance for BASELINE config 3 (128 x 128 frames, 41 x 41 kernel: Fy = Fx = 160 = 10 x 16, M = 80 =
+// 16 x 5) -- the plan's shapes and radices are compile-time facts (index arithmetic and radix dispatch fold away: the
+// kernel fits 128 VGPRs) and the workgroup has NT = 1024 threads: the passes of 640 - 810 items take ONE round of
+// threads instead of two half-empty ones, at four waves per SIMD instead of two.
+template <bool XP, int NT>
+__device__ __forceinline__ void psf_conv_body(const PsfArgs &a, const FftPlan &p_in, float *G, long long *stamps_all)
 {
+    FftPlan p = p_in;
+    if (XP) {
+        p.H = 128; p.W = 128; p.Fy = 160; p.Fx = 160; p.M = 80; p.RS = 81;
+        p.R1y = 10; p.R2y = 16; p.R1x = 16; p.R2x = 5; p.dma_image = 1;
+        p.tab_off = fft_tab_off(160, 81, 128, 128, true);
+    }
     extern __shared__ __align__(16) float2 fft_lds[];
     const int B = a.B;
     const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
@@ -684,27 +698,28 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, fl
     const float2 *img = (const float2 *)(a.images + plane * HW);
     const float2 *wgt = a.weights ? (const float2 *)(a.weights + plane * HW) : nullptr;
     // model plane -> rows < H (pixel pairs), zeros up to column M
-    const FftLds l = fft_lds_setup(fft_lds, p);
-    float2 mreg[SC_FFT_PF];
+    const FftLds l = fft_lds_setup<NT>(fft_lds, p);
+    constexpr int PF = SC_FFT_PF * SC_FFT_NT / NT;      // the same 8192 pairs in registers at kernel start
+    float2 mreg[PF];
 #pragma unroll
-    for (int j = 0; j < SC_FFT_PF; ++j) {
-        const int u = threadIdx.x + j * SC_FFT_NT;
+    for (int j = 0; j < PF; ++j) {
+        const int u = threadIdx.x + j * NT;
         mreg[j] = u < H * Wh ? gp[u] : make_float2(0.f, 0.f);
     }
-    __shared__ double red[SC_FFT_NT / SC_WAVE];
+    __shared__ double red[NT / SC_WAVE];
     {
         const float rcp = 1.0f / (float)M;
-        for (int u = threadIdx.x; u < H * M; u += SC_FFT_NT) {
+        for (int u = threadIdx.x; u < H * M; u += NT) {
             const int y = fast_div(u, rcp), n = u - y * M;
             if (n >= Wh) l.A[y * p.RS + n] = make_float2(0.f, 0.f);
         }
         const float rcpw = 1.0f / (float)Wh;
 #pragma unroll
-        for (int j = 0; j < SC_FFT_PF; ++j) {
-            const int u = threadIdx.x + j * SC_FFT_NT;
+        for (int j = 0; j < PF; ++j) {
+            const int u = threadIdx.x + j * NT;
             if (u < H * Wh) { const int y = fast_div(u, rcpw), n = u - y * Wh; l.A[y * p.RS + n] = mreg[j]; }
         }
-        for (int u = threadIdx.x + SC_FFT_PF * SC_FFT_NT; u < H * Wh; u += SC_FFT_NT) {
+        for (int u = threadIdx.x + PF * NT; u < H * Wh; u += NT) {
             const int y = fast_div(u, rcpw), n = u - y * Wh;
             l.A[y * p.RS + n] = gp[u];
         }
@@ -714,13 +729,13 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, fl
     double loss = 0;
     FFT_STAMP(31);
     // the image is requested after the render's column stage: in flight under the next row pass
-    fft_conv_core<false>(l, p, khat, stamps, [&]() { if (p.dma_image) fft_dma_image(l, p, a.images + plane * HW); });
-    fft_residual(l, p, img, wgt, a.weight_scalar, loss);
+    fft_conv_core<false, NT>(l, p, khat, stamps, [&]() { if (p.dma_image) fft_dma_image<NT>(l, p, a.images + plane * HW); });
+    fft_residual<NT>(l, p, img, wgt, a.weight_scalar, loss);
     FFT_STAMP(7);
-    fft_conv_core<true>(l, p, khat, stamps ? stamps + 8 : nullptr, []() {});
+    fft_conv_core<true, NT>(l, p, khat, stamps ? stamps + 8 : nullptr, []() {});
     {
         const float rcpw = 1.0f / (float)Wh;
-        for (int u = threadIdx.x; u < H * Wh; u += SC_FFT_NT) {
+        for (int u = threadIdx.x; u < H * Wh; u += NT) {
             const int y = fast_div(u, rcpw), n = u - y * Wh;
             gp[u] = l.A[y * p.RS + n];
         }
@@ -732,7 +747,17 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, fl
     __syncthreads();
     if (threadIdx.x == 0) {
         double r = 0;
-        for (int w = 0; w < SC_FFT_NT / SC_WAVE; ++w) r += red[w];
+        for (int w = 0; w < NT / SC_WAVE; ++w) r += red[w];
         a.loss_part[plane] = 0.5 * r;
     }
+}
+
+__global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, float *G, long long *stamps_all)
+{
+    psf_conv_body<false, SC_FFT_NT>(a, p, G, stamps_all);
+}
+#define SC_FFT_NT_X 1024
+__global__ __launch_bounds__(SC_FFT_NT_X) void k_psf_conv_x128(PsfArgs a, FftPlan p, float *G, long long *stamps_all)
+{
+    psf_conv_body<true, SC_FFT_NT_X>(a, p, G, stamps_all);
 }

@@ -963,6 +963,16 @@ static void split_views(const scarlet_batch *b, scarlet_batch v[2])
     v[1] = batch_view(b, n0, b->S - n0, ws + align256(psf_layout(&v[0]).total));
 }
 
+// diagnostics (STAMPS switch): byte offset, inside the batch's workspace, of k_psf_conv's phase stamps
+// ([S][B][32] int64 shader-clock values), or -1 when the batch has none
+extern "C" int64_t scarlet_debug_psf_stamps_offset(const scarlet_batch *b)
+{
+    if (!b || !b->diff_kernel || b->psf_h <= 0 || b->psf_w <= 0 || !opt(OPT_STAMPS)) return -1;
+    FftPlan p;
+    if (!psf_use_lds(b, &p)) return -1;
+    return psf_layout(b).stamps;
+}
+
 extern "C" int scarlet_batch_pipelines(const scarlet_batch *b)
 {
     if (!b) return 0;
@@ -1213,6 +1223,13 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
             hipLaunchKernelGGL(k_psf_model, dim3((b->H * b->W + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
         long long *stamps = opt(OPT_STAMPS) ? (long long *)((char *)b->workspace + l.stamps) : nullptr;
         fp.stagger_wgs = 0;
+        // BASELINE config 3's plan has an exact-shape instance with 1024 threads per workgroup (fftconv.h)
+        const bool x128 = fp.H == 128 && fp.W == 128 && fp.Fy == 160 && fp.Fx == 160 && fp.M == 80 && fp.RS == 81 && fp.R1y == 10 &&
+                          fp.R2y == 16 && fp.R1x == 16 && fp.R2x == 5 && fp.dma_image == 1 && !opt(OPT_NO_EXACT);
+        if (x128) {
+            if ((rc = allow_lds(k_psf_conv_x128, lds))) return rc;
+            hipLaunchKernelGGL(k_psf_conv_x128, dim3(groups * 8 * b->B), dim3(SC_FFT_NT_X), lds, st, a, fp, a.real, stamps);
+        } else
         hipLaunchKernelGGL(k_psf_conv, dim3(groups * 8 * b->B), dim3(SC_FFT_NT), lds, st, a, fp, a.real, stamps);
         prof_stop(st);
         // (the gradient kernels below read G through the same geometry struct: compact planes, no offset)

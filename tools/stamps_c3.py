@@ -9,8 +9,10 @@ g = runpy.run_path(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"),
 b = g["b"]
 n = b.S * b.B * 32
 ws = b.workspace
-# the stamps region is the last one of the PSF layout (scarlet_hip.hip psf_layout): total - 256 - planes*32*8
-off = ws.numel() - 256 - ((n * 8 + 255) // 256) * 256
+import ctypes
+from scarlet_amd import _lib
+off = int(_lib.lib.scarlet_debug_psf_stamps_offset(ctypes.byref(b._c)))
+assert off >= 0, "no stamps region (SCARLET_STAMPS=1 must be set before the library is loaded)"
 st = ws[off:off + n * 8].view(torch.int64).view(-1, 32).cpu().numpy()
 ok = st[:, 15] > 0
 st = st[ok]
