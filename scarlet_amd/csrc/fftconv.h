@@ -72,36 +72,46 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+// Complex numbers are 2-vectors of the compiler's native vector type: (re, im) in one aligned register pair, so that
+// additions, scalings and the two halves of a complex product each become ONE packed instruction (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32; the swap of re and im rides in the instruction's op_sel bits).  What the packed forms
+// cannot express is a sign on ONE lane, so every product is written as  a * c + swap(a) * (-s, s)  with the pair
+// (-s, s) prepared once: compile-time for the codelets' own twiddles, a second pair of the table entry for the
+// twiddles read from LDS (cf4 = (c, s, -s, s)); the conjugate product takes the same pair swapped.  (With
+// HIP's float2 and scalar re / im expressions the vectoriser found the packed forms only partly: a product cost five
+// instructions -- one of them a move that merged two half-used results -- and 29 % of the kernel's vector
+// instructions were moves; measured on k_psf_conv_x128, profiles/r03_notes.md.)
+typedef float cf __attribute__((ext_vector_type(2)));
+typedef float cf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cf swp(cf a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ cf vfma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ cf cf_zero() { return cf{0.f, 0.f}; }
+// a * w, a * conj(w) for a table twiddle w4 = (c, s, -s, s)
+__device__ __forceinline__ cf cmul_t(cf a, cf4 w) { return vfma(swp(a), w.zw, a * w.xx); }
+__device__ __forceinline__ cf cmul_conj_t(cf a, cf4 w) { return vfma(swp(a), w.wz, a * w.xx); }
+// a * k, a * conj(k) for a plain complex k (K-hat from global memory): the pair (-k.y, k.y) costs one instruction
+__device__ __forceinline__ cf cmul(cf a, cf k) { return vfma(swp(a), k.yy * cf{-1.f, 1.f}, a * k.xx); }
+__device__ __forceinline__ cf cmul_conj(cf a, cf k) { return vfma(swp(a), k.yy * cf{1.f, -1.f}, a * k.xx); }
+__device__ __forceinline__ cf cconj(cf a) { return a * cf{1.f, -1.f}; }
+// t - i d (forward quarter turn of d) / t + i d
+template <bool INV> __device__ __forceinline__ cf add_rot(cf t, cf d)
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)     // a * conj(b)
-{
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-// multiplication by -i (forward quarter turn) / +i
-template <bool INV> __device__ __forceinline__ float2 rot90(float2 a)
-{
-    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+    return vfma(swp(d), INV ? cf{-1.f, 1.f} : cf{1.f, -1.f}, t);
 }
 
 // v * w_N^J (forward: e^{-2 pi i J / N}; INV: conjugate), J and N compile-time
 template <int N, int J, bool INV>
-__device__ __forceinline__ float2 twiddle_const(float2 v)
+__device__ __forceinline__ cf twiddle_const(cf v)
 {
     constexpr int j = ((J % N) + N) % N;
     if constexpr (j == 0) return v;
-    else if constexpr (4 * j == N) return rot90<INV>(v);
-    else if constexpr (2 * j == N) return make_float2(-v.x, -v.y);
-    else if constexpr (4 * j == 3 * N) return rot90<!INV>(v);
+    else if constexpr (4 * j == N) return swp(v) * (INV ? cf{-1.f, 1.f} : cf{1.f, -1.f});
+    else if constexpr (2 * j == N) return -v;
+    else if constexpr (4 * j == 3 * N) return swp(v) * (INV ? cf{1.f, -1.f} : cf{-1.f, 1.f});
     else {
         constexpr float c = (float)cx_cos2pi(j, N);
         constexpr float s = (float)(INV ? cx_sin2pi(j, N) : -cx_sin2pi(j, N));
-        return make_float2(v.x * c - v.y * s, v.x * s + v.y * c);
+        return vfma(swp(v), cf{-s, s}, v * c);
     }
 }
 
@@ -118,50 +128,49 @@ constexpr int first_factor(int n)
 // ---- radix codelets: in-register DFT of v[0..N-1], natural order in and out
 template <int N, bool INV> struct Dft;
 
-template <bool INV> struct Dft<1, INV> { static __device__ __forceinline__ void run(float2 (&)[1]) {} };
+template <bool INV> struct Dft<1, INV> { static __device__ __forceinline__ void run(cf (&)[1]) {} };
 template <bool INV> struct Dft<2, INV> {
-    static __device__ __forceinline__ void run(float2 (&v)[2])
+    static __device__ __forceinline__ void run(cf (&v)[2])
     {
-        const float2 a = v[0], b = v[1];
-        v[0] = cadd(a, b); v[1] = csub(a, b);
+        const cf a = v[0], b = v[1];
+        v[0] = a + b; v[1] = a - b;
     }
 };
 template <bool INV> struct Dft<4, INV> {
-    static __device__ __forceinline__ void run(float2 (&v)[4])
+    static __device__ __forceinline__ void run(cf (&v)[4])
     {
-        const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = rot90<INV>(csub(v[1], v[3]));
-        v[0] = cadd(t0, t2); v[2] = csub(t0, t2); v[1] = cadd(t1, t3); v[3] = csub(t1, t3);
+        const cf t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
+        v[0] = t0 + t2; v[2] = t0 - t2; v[1] = add_rot<INV>(t1, d); v[3] = add_rot<!INV>(t1, d);
     }
 };
 // odd primes 3, 5, 7: pairs x_j +- x_{P-j}
 template <int P, bool INV> struct DftOddPrime {
-    static __device__ __forceinline__ void run(float2 (&v)[P])
+    static __device__ __forceinline__ void run(cf (&v)[P])
     {
         constexpr int Hf = (P - 1) / 2;
-        float2 t[Hf], d[Hf];
+        cf t[Hf], d[Hf];
         static_for<0, Hf>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            t[j] = cadd(v[j + 1], v[P - 1 - j]);
-            d[j] = csub(v[j + 1], v[P - 1 - j]);
+            t[j] = v[j + 1] + v[P - 1 - j];
+            d[j] = v[j + 1] - v[P - 1 - j];
         });
-        const float2 x0 = v[0];
-        float2 sum = x0;
-        static_for<0, Hf>([&](auto jc) { sum = cadd(sum, t[decltype(jc)::value]); });
+        const cf x0 = v[0];
+        cf sum = x0;
+        static_for<0, Hf>([&](auto jc) { sum = sum + t[decltype(jc)::value]; });
         v[0] = sum;
         static_for<1, Hf + 1>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            float2 m = x0, n = make_float2(0.f, 0.f);
+            cf m = x0, n = cf_zero();
             static_for<0, Hf>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 constexpr float c = (float)cx_cos2pi((j + 1) * k, P);
                 constexpr float s = (float)cx_sin2pi((j + 1) * k, P);
-                m.x += c * t[j].x; m.y += c * t[j].y;
-                n.x += s * d[j].x; n.y += s * d[j].y;
+                m = vfma(t[j], cf{c, c}, m);
+                n = j == 0 ? d[j] * s : vfma(d[j], cf{s, s}, n);
             });
             // forward: X_k = m - i n, X_{P-k} = m + i n
-            const float2 r = rot90<INV>(n);
-            v[k] = cadd(m, r);
-            v[P - k] = csub(m, r);
+            v[k] = add_rot<INV>(m, n);
+            v[P - k] = add_rot<!INV>(m, n);
         });
     }
 };
@@ -173,12 +182,12 @@ template <bool INV> struct Dft<7, INV> : DftOddPrime<7, INV> {};
 template <int N, bool INV> struct Dft {
     static constexpr int A = first_factor(N), B = N / A;
     static_assert(A > 1 && A < N, "unsupported radix");
-    static __device__ __forceinline__ void run(float2 (&v)[N])
+    static __device__ __forceinline__ void run(cf (&v)[N])
     {
-        float2 u[N];
+        cf u[N];
         static_for<0, B>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            float2 t[A];
+            cf t[A];
             static_for<0, A>([&](auto ac) { constexpr int a = decltype(ac)::value; t[a] = v[B * a + b]; });
             Dft<A, INV>::run(t);
             static_for<0, A>([&](auto kc) {
@@ -188,7 +197,7 @@ template <int N, bool INV> struct Dft {
         });
         static_for<0, A>([&](auto kc) {
             constexpr int ka = decltype(kc)::value;
-            float2 w[B];
+            cf w[B];
             static_for<0, B>([&](auto bc) { constexpr int b = decltype(bc)::value; w[b] = u[ka * B + b]; });
             Dft<B, INV>::run(w);
             static_for<0, B>([&](auto bc) { constexpr int kb = decltype(bc)::value; v[ka + A * kb] = w[kb]; });
@@ -211,20 +220,21 @@ struct FftPlan {
     int stagger_wgs;                    // k_psf_conv: number of workgroups of the first generation (CUs of the device)
     int tab_off;                        // LDS offset (float2) of the tables: behind the plane and the image staging area
     int dma_image;                      // k_psf_conv: the image is staged in LDS by LDS-DMA (rows >= H + the space behind the plane)
-    const float2 *tables;               // device: twy[Fy] = w_Fy^j, twm[M] = w_M^j, twx[M/2 + 1] = w_Fx^k, then posx[M] (uint16),
-                                        // then the column pairs in position order: twp[NP] and pair[NP] = {ra, rb, cb, 0} (uint16 x 4)
+    const float2 *tables;               // device: twiddles as (c, s, -s, s) quadruples (cf4) -- twy[Fy] = w_Fy^j, twm[M] = w_M^j,
+                                        // twx[NP] = w_Fx^k, twp[NP] = twx in the order of the column pairs -- then posx[M]
+                                        // (uint16) and the column pairs in position order: pair[NP] = {ra, rb, cb, 0} (uint16 x 4)
 };
 // NP = M/2 + 1 pairs (k, M - k) of spectrum columns.  The fused column passes visit them in the order of their
 // POSITION in the permuted row (ra ascending; then rb = const - ra descends): consecutive lanes read consecutive
 // float2, where the order of k walked the row at stride R2x (two-way bank conflicts on every paired read).
-__host__ __device__ inline int fft_table_float2s(int Fy, int M) { return Fy + M + (M / 2 + 1) + (M + 3) / 4 + 2 * (M / 2 + 1); }
+__host__ __device__ inline int fft_table_float2s(int Fy, int M) { return 2 * (Fy + M + 2 * (M / 2 + 1)) + (M + 3) / 4 + (M / 2 + 1); }
 // LDS of the transform kernels: the plane [Fy][RS], then the tables.  k_psf_conv additionally stages the image
 // plane (H x W floats) from row H on -- rows >= H are idle between the render's column stage and the adjoint's,
 // which is when the residual needs the image -- so its tables sit behind max(plane, H rows + image).
 __host__ __device__ inline int fft_tab_off(int Fy, int RS, int H, int W, bool stage_image)
 {
     const int plane = Fy * RS, staged = H * RS + (H * W + 1) / 2;
-    return (stage_image && staged > plane) ? staged : plane;
+    return (((stage_image && staged > plane) ? staged : plane) + 1) & ~1;       // the tables are read 16 bytes at a time
 }
 __host__ __device__ inline size_t fft_lds_bytes(int Fy, int M, int RS, int H = 0, int W = 0, bool stage_image = false)
 {
@@ -237,7 +247,7 @@ __device__ __forceinline__ int fast_div(int u, float rcp_d) { return (int)(((flo
 // one pass over `nlines` independent 1-D transforms: item (line, j) loads v[q] = A[line*ls + j*joff + q*qs],
 // q < R, transforms, multiplies output k by (conj) tw[j k] when use_tw, and stores back in place.
 template <int R, bool INV, int NT = SC_FFT_NT>
-__device__ __forceinline__ void fft_items(float2 *A, int nlines, int ls, int J, int joff, int qs, const float2 *tw,
+__device__ __forceinline__ void fft_items(cf *A, int nlines, int ls, int J, int joff, int qs, const cf4 *tw,
                                           bool use_tw, bool line_fastest)
 {
     const int total = nlines * J;
@@ -246,16 +256,16 @@ __device__ __forceinline__ void fft_items(float2 *A, int nlines, int ls, int J, 
         int line, j;
         if (line_fastest) { j = fast_div(u, rcp); line = u - j * nlines; }
         else { line = fast_div(u, rcp); j = u - line * J; }
-        float2 *p = A + line * ls + j * joff;
-        float2 v[R];
+        cf *p = A + line * ls + j * joff;
+        cf v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = p[q * qs];
         Dft<R, INV>::run(v);
         if (use_tw) {
 #pragma unroll
             for (int k = 1; k < R; ++k) {
-                const float2 w = tw[j * k];
-                v[k] = INV ? cmul_conj(v[k], w) : cmul(v[k], w);
+                const cf4 w = tw[j * k];
+                v[k] = INV ? cmul_conj_t(v[k], w) : cmul_t(v[k], w);
             }
         }
 #pragma unroll
@@ -264,7 +274,7 @@ __device__ __forceinline__ void fft_items(float2 *A, int nlines, int ls, int J, 
 }
 
 template <bool INV, int NT = SC_FFT_NT>
-__device__ __forceinline__ void fft_pass(int R, float2 *A, int nlines, int ls, int J, int joff, int qs, const float2 *tw,
+__device__ __forceinline__ void fft_pass(int R, cf *A, int nlines, int ls, int J, int joff, int qs, const cf4 *tw,
                                          bool use_tw, bool line_fastest)
 {
     switch (R) {
@@ -282,12 +292,12 @@ __host__ __device__ inline bool fft_radix_ok(int r)
 }
 
 // forward / inverse 1-D transforms of `nlines` lines (es = element stride, ls = line stride), in place
-__device__ __forceinline__ void fft_lines_fwd(float2 *A, int nlines, int ls, int es, int R1, int R2, const float2 *tw, bool lf)
+__device__ __forceinline__ void fft_lines_fwd(cf *A, int nlines, int ls, int es, int R1, int R2, const cf4 *tw, bool lf)
 {
     fft_pass<false>(R1, A, nlines, ls, R2, es, R2 * es, tw, true, lf);          // A
     fft_pass<false>(R2, A, nlines, ls, R1, R2 * es, es, tw, false, lf);         // B
 }
-__device__ __forceinline__ void fft_lines_inv(float2 *A, int nlines, int ls, int es, int R1, int R2, const float2 *tw, bool lf)
+__device__ __forceinline__ void fft_lines_inv(cf *A, int nlines, int ls, int es, int R1, int R2, const cf4 *tw, bool lf)
 {
     fft_pass<true>(R2, A, nlines, ls, R1, R2 * es, es, tw, true, lf);           // B^-1
     fft_pass<true>(R1, A, nlines, ls, R2, es, R2 * es, tw, false, lf);          // A^-1
@@ -295,8 +305,8 @@ __device__ __forceinline__ void fft_lines_inv(float2 *A, int nlines, int ls, int
 
 struct FftPair { unsigned short ra, rb, cb, pad; };    // read positions of the pair, write position of its second member
 struct FftLds {
-    float2 *A;                  // [Fy][RS]
-    const float2 *twy, *twm, *twx, *twp;
+    cf *A;                      // [Fy][RS]
+    const cf4 *twy, *twm, *twx, *twp;
     const unsigned short *posx;
     const FftPair *pair;
 };
@@ -304,15 +314,36 @@ template <int NT = SC_FFT_NT>
 __device__ __forceinline__ FftLds fft_lds_setup(float2 *lds, const FftPlan &p)
 {
     FftLds l;
-    l.A = lds;
+    l.A = reinterpret_cast<cf *>(lds);
     float2 *t = lds + p.tab_off;
-    const int nt = fft_table_float2s(p.Fy, p.M);
+    const int nt = fft_table_float2s(p.Fy, p.M), NP = p.M / 2 + 1;
     for (int i = threadIdx.x; i < nt; i += NT) t[i] = p.tables[i];
-    l.twy = t; l.twm = t + p.Fy; l.twx = l.twm + p.M;
-    l.posx = (const unsigned short *)(l.twx + (p.M / 2 + 1));
-    l.twp = l.twx + (p.M / 2 + 1) + (p.M + 3) / 4;
-    l.pair = (const FftPair *)(l.twp + (p.M / 2 + 1));
+    l.twy = reinterpret_cast<const cf4 *>(t); l.twm = l.twy + p.Fy; l.twx = l.twm + p.M; l.twp = l.twx + NP;
+    l.posx = (const unsigned short *)(l.twp + NP);
+    l.pair = (const FftPair *)(t + 2 * (p.Fy + p.M + 2 * NP) + (p.M + 3) / 4);
     return l;
+}
+
+// real rows: a = Z[k], b = Z[M-k] of the packed transform -> X[k], X[M-k] (w = w_Fx^k)
+//   X[k] = (a + b*)/2 - i w (a - b*)/2 ;  X[M-k] = (b + a*)/2 + i w* (b - a*)/2 = conj(s) - i conj(w d)
+__device__ __forceinline__ void untangle_pair(cf a, cf b, cf4 w, cf &xa, cf &xb)
+{
+    const cf h = a * 0.5f;
+    const cf s = vfma(b, cf{0.5f, -0.5f}, h);         // (a + b*)/2
+    const cf d = vfma(b, cf{-0.5f, 0.5f}, h);         // (a - b*)/2
+    const cf wd = cmul_t(d, w);
+    xa = vfma(swp(wd), cf{1.f, -1.f}, s);             // s - i wd
+    xb = vfma(s, cf{1.f, -1.f}, -swp(wd));            // (s.x - wd.y, -s.y - wd.x)
+}
+// the inverse: xk = X[k], xm = X[M-k] -> Z[k] = E + i O, Z[M-k] = conj(E) + i conj(O), E = (xk + xm*)/2, O = (xk - xm*)/2 conj(w)
+__device__ __forceinline__ void tangle_pair(cf xk, cf xm, cf4 w, cf &zk, cf &zm)
+{
+    const cf h = xk * 0.5f;
+    const cf E = vfma(xm, cf{0.5f, -0.5f}, h);
+    const cf D = vfma(xm, cf{-0.5f, 0.5f}, h);
+    const cf O = cmul_conj_t(D, w);
+    zk = vfma(swp(O), cf{-1.f, 1.f}, E);              // (E.x - O.y, E.y + O.x)
+    zm = vfma(E, cf{1.f, -1.f}, swp(O));              // (E.x + O.y, -E.y + O.x)
 }
 
 // real rows after the length-M complex FFT: untangle the pairs (k, M - k) in place (tools/fft_proto.py rows_fwd)
@@ -323,24 +354,20 @@ __device__ __forceinline__ void fft_rows_untangle(const FftLds &l, const FftPlan
     const float rcp = 1.0f / (float)half;
     for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
         const int y = fast_div(u, rcp), k = u - y * half;
-        float2 *r = l.A + y * p.RS;
+        cf *r = l.A + y * p.RS;
         if (k == 0) {
-            const float2 z = r[l.posx[0]];
-            r[l.posx[0]] = make_float2(z.x + z.y, 0.f);
-            r[M] = make_float2(z.x - z.y, 0.f);
+            const cf z = r[l.posx[0]];
+            r[l.posx[0]] = cf{z.x + z.y, 0.f};
+            r[M] = cf{z.x - z.y, 0.f};
         } else if (2 * k == M) {
             const int q = l.posx[k];
             r[q] = cconj(r[q]);
         } else if (2 * k < M) {
             const int pa = l.posx[k], pb = l.posx[M - k];
-            const float2 a = r[pa], b = r[pb], w = l.twx[k];
-            // X[k] = (a + b*)/2 - i/2 w (a - b*);  X[M-k] = (b + a*)/2 + i/2 w* (b - a*)
-            const float2 s = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));     // (a + b*)/2
-            const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));     // (a - b*)/2
-            const float2 wd = cmul(w, d);                                              // w d ; -i (wd) = (wd.y, -wd.x)
-            r[pa] = make_float2(s.x + wd.y, s.y - wd.x);
-            // (b + a*)/2 = conj(s);  (b - a*)/2 = -conj(d);  + i w* (-conj d) = -i conj(w d) = -i (wd.x, -wd.y) = (-wd.y, -wd.x)
-            r[pb] = make_float2(s.x - wd.y, -s.y - wd.x);
+            cf xa, xb;
+            untangle_pair(r[pa], r[pb], l.twx[k], xa, xb);
+            r[pa] = xa;
+            r[pb] = xb;
         }
     }
     __syncthreads();
@@ -353,22 +380,19 @@ __device__ __forceinline__ void fft_rows_tangle(const FftLds &l, const FftPlan &
     const float rcp = 1.0f / (float)half;
     for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
         const int y = fast_div(u, rcp), k = u - y * half;
-        float2 *r = l.A + y * p.RS;
+        cf *r = l.A + y * p.RS;
         if (k == 0) {
             const float x0 = r[l.posx[0]].x, xm = r[M].x;
-            r[l.posx[0]] = make_float2(0.5f * (x0 + xm), 0.5f * (x0 - xm));
+            r[l.posx[0]] = cf{0.5f * (x0 + xm), 0.5f * (x0 - xm)};
         } else if (2 * k == M) {
             const int q = l.posx[k];
             r[q] = cconj(r[q]);
         } else if (2 * k < M) {
             const int pa = l.posx[k], pb = l.posx[M - k];
-            const float2 xk = r[pa], xm = r[pb], w = l.twx[k];
-            const float2 E = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));      // (X[k] + X[M-k]*)/2
-            const float2 D = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));      // (X[k] - X[M-k]*)/2
-            const float2 O = cmul_conj(D, w);                                              // D conj(w)
-            // Z[k] = E + i O ; Z[M-k] = conj(E) + i conj(O)
-            r[pa] = make_float2(E.x - O.y, E.y + O.x);
-            r[pb] = make_float2(E.x + O.y, -E.y + O.x);
+            cf zk, zm;
+            tangle_pair(r[pa], r[pb], l.twx[k], zk, zm);
+            r[pa] = zk;
+            r[pb] = zm;
         }
     }
     __syncthreads();
@@ -396,8 +420,8 @@ __device__ __forceinline__ void fft_spec_mul(const FftLds &l, const FftPlan &p, 
     const float rcp = 1.0f / (float)cols;
     for (int u = threadIdx.x; u < total; u += SC_FFT_NT) {
         const int y = fast_div(u, rcp), c = u - y * cols;
-        const float2 k = khat[u];
-        float2 *q = l.A + y * p.RS + c;
+        const cf k = reinterpret_cast<const cf *>(khat)[u];
+        cf *q = l.A + y * p.RS + c;
         *q = CONJ ? cmul_conj(*q, k) : cmul(*q, k);
     }
     __syncthreads();
@@ -414,7 +438,7 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_fft_khat(const float *ker, FftPla
     const int M = p.M, cols = M + 1;
     for (int u = threadIdx.x; u < p.Fy * p.RS; u += SC_FFT_NT) {
         const int iy = u / p.RS, n = u - iy * p.RS;
-        float2 v = make_float2(0.f, 0.f);
+        cf v = cf_zero();
         if (n < M) {
             const int q = pos_mod(iy - p.oky, p.Fy);
             if (q < p.Py) {
@@ -430,7 +454,7 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_fft_khat(const float *ker, FftPla
     float2 *out = khat + (size_t)plane * p.Fy * cols;
     for (int u = threadIdx.x; u < p.Fy * cols; u += SC_FFT_NT) {
         const int y = u / cols, c = u - y * cols;
-        const float2 v = l.A[y * p.RS + c];
+        const cf v = l.A[y * p.RS + c];
         out[u] = make_float2(v.x * p.scale, v.y * p.scale);
     }
 }
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_fft_convolve(const float *in, Fft
     const float *ip = in + (size_t)plane * H * W;
     for (int u = threadIdx.x; u < p.Fy * p.RS; u += SC_FFT_NT) {
         const int y = u / p.RS, n = u - y * p.RS;
-        float2 v = make_float2(0.f, 0.f);
+        cf v = cf_zero();
         if (y < H && n < Wh) {
             v.x = ip[y * W + 2 * n];
             if (2 * n + 1 < W) v.y = ip[y * W + 2 * n + 1];
@@ -458,7 +482,7 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_fft_convolve(const float *in, Fft
     float *op = out + (size_t)plane * H * W;
     for (int u = threadIdx.x; u < H * W; u += SC_FFT_NT) {
         const int y = u / W, x = u - y * W;
-        const float2 v = l.A[y * p.RS + (x >> 1)];
+        const cf v = l.A[y * p.RS + (x >> 1)];
         op[u] = (x & 1) ? v.y : v.x;
     }
 }
@@ -484,26 +508,22 @@ __device__ __forceinline__ void cols_A_untangle(const FftLds &l, const FftPlan &
         const int n2 = fast_div(u, rcp), i = u - n2 * NP;
         const FftPair pr = l.pair[i];
         const int ra = pr.ra, rb = pr.rb, cb = pr.cb;
-        const float2 w = l.twp[i];
-        float2 xa[R], xb[R];
+        const cf4 w = l.twp[i];
+        cf xa[R], xb[R];
 #pragma unroll
         for (int n1 = 0; n1 < R; ++n1) {
             const int r = R2 * n1 + n2;
-            float2 a = make_float2(0.f, 0.f), b = a;
+            cf a = cf_zero(), b = a;
             if (r < H) { a = l.A[r * RS + ra]; b = l.A[r * RS + rb]; }
-            const float2 sm = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
-            const float2 df = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
-            const float2 wd = cmul(w, df);
-            xa[n1] = make_float2(sm.x + wd.y, sm.y - wd.x);
-            xb[n1] = make_float2(sm.x - wd.y, -sm.y - wd.x);
+            untangle_pair(a, b, w, xa[n1], xb[n1]);
         }
         Dft<R, false>::run(xa);
         Dft<R, false>::run(xb);
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) {
-            float2 va = xa[k1], vb = xb[k1];
-            if (k1 > 0) { const float2 t = l.twy[n2 * k1]; va = cmul(va, t); vb = cmul(vb, t); }
-            float2 *q = l.A + (R2 * k1 + n2) * RS;
+            cf va = xa[k1], vb = xb[k1];
+            if (k1 > 0) { const cf4 t = l.twy[n2 * k1]; va = cmul_t(va, t); vb = cmul_t(vb, t); }
+            cf *q = l.A + (R2 * k1 + n2) * RS;
             q[ra] = va;
             q[cb] = vb;               // k == M/2: the same value at the same place
         }
@@ -519,9 +539,9 @@ __device__ __forceinline__ void cols_B_mul_Binv(const FftLds &l, const FftPlan &
     const float rcp = 1.0f / (float)cols;
     for (int u = threadIdx.x; u < total; u += NT) {
         const int k1 = fast_div(u, rcp), c = u - k1 * cols;
-        float2 *q = l.A + (R * k1) * RS + c;
-        const float2 *kq = khat + (R * k1) * cols + c;
-        float2 v[R], kk[R];
+        cf *q = l.A + (R * k1) * RS + c;
+        const cf *kq = reinterpret_cast<const cf *>(khat) + (R * k1) * cols + c;
+        cf v[R], kk[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) kk[r] = kq[r * cols];
 #pragma unroll
@@ -531,7 +551,7 @@ __device__ __forceinline__ void cols_B_mul_Binv(const FftLds &l, const FftPlan &
         for (int r = 0; r < R; ++r) v[r] = CONJ ? cmul_conj(v[r], kk[r]) : cmul(v[r], kk[r]);
         Dft<R, true>::run(v);
 #pragma unroll
-        for (int r = 1; r < R; ++r) v[r] = cmul_conj(v[r], l.twy[r * k1]);
+        for (int r = 1; r < R; ++r) v[r] = cmul_conj_t(v[r], l.twy[r * k1]);
 #pragma unroll
         for (int r = 0; r < R; ++r) q[r * RS] = v[r];
     }
@@ -549,11 +569,11 @@ __device__ __forceinline__ void cols_Ainv_tangle(const FftLds &l, const FftPlan 
         const FftPair pr = l.pair[i];
         const int ra = pr.ra, rb = pr.rb, cb = pr.cb;
         const bool first = cb == M;                              // (k = 0: its second member lives in the extra slot M)
-        const float2 w = l.twp[i];
-        float2 xa[R], xb[R];
+        const cf4 w = l.twp[i];
+        cf xa[R], xb[R];
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) {
-            const float2 *q = l.A + (R2 * k1 + n2) * RS;
+            const cf *q = l.A + (R2 * k1 + n2) * RS;
             xa[k1] = q[ra];
             xb[k1] = q[cb];
         }
@@ -563,13 +583,9 @@ __device__ __forceinline__ void cols_Ainv_tangle(const FftLds &l, const FftPlan 
         for (int n1 = 0; n1 < R; ++n1) {
             const int r = R2 * n1 + n2;
             if (r < H) {
-                float2 xk = xa[n1], xm = xb[n1];
+                cf xk = xa[n1], xm = xb[n1], zk, zm;
                 if (first) { xk.y = 0.f; xm.y = 0.f; }             // X[0], X[M] of a real signal are real
-                const float2 E = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
-                const float2 D = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
-                const float2 O = cmul_conj(D, w);
-                const float2 zk = make_float2(E.x - O.y, E.y + O.x);
-                const float2 zm = make_float2(E.x + O.y, -E.y + O.x);
+                tangle_pair(xk, xm, w, zk, zm);
                 l.A[r * RS + rb] = zm;                             // k == 0, M/2: same place as zk, written first
                 l.A[r * RS + ra] = zk;
             }
@@ -603,15 +619,16 @@ __device__ __forceinline__ void fft_residual(const FftLds &l, const FftPlan &p, 
 {
     const int Wh = p.W >> 1, npairs = p.H * Wh;
     const float rcp = 1.0f / (float)Wh;
-    const float2 *stage = l.A + p.H * p.RS;           // the image as the LDS-DMA left it: [H][W/2] pairs, lane-linear
+    const cf *stage = l.A + p.H * p.RS;               // the image as the LDS-DMA left it: [H][W/2] pairs, lane-linear
+    const cf *imgv = reinterpret_cast<const cf *>(img), *wgtv = reinterpret_cast<const cf *>(wgt);
     for (int u = threadIdx.x; u < npairs; u += NT) {
         const int y = fast_div(u, rcp), n = u - y * Wh;
-        float2 *q = l.A + y * p.RS + n;
-        const float2 r = *q, im = p.dma_image ? stage[u] : img[u];
-        const float2 w = wgt ? wgt[u] : make_float2(wscalar, wscalar);
-        const float dx = w.x * (r.x - im.x), dy = w.y * (r.y - im.y);
-        loss += (double)dx * (double)dx + (double)dy * (double)dy;
-        *q = make_float2(w.x * dx, w.y * dy);
+        cf *q = l.A + y * p.RS + n;
+        const cf r = *q, im = p.dma_image ? stage[u] : imgv[u];
+        const cf w = wgt ? wgtv[u] : cf{wscalar, wscalar};
+        const cf d = w * (r - im);
+        loss += (double)d.x * (double)d.x + (double)d.y * (double)d.y;
+        *q = w * d;
     }
     // the inverse transform leaves (tiny) values in columns W/2 .. M-1 of the rows: the adjoint's input is zero there
     const int pad = p.M - Wh;
@@ -619,7 +636,7 @@ __device__ __forceinline__ void fft_residual(const FftLds &l, const FftPlan &p, 
         const float rcp2 = 1.0f / (float)pad;
         for (int u = threadIdx.x; u < p.H * pad; u += NT) {
             const int y = fast_div(u, rcp2), n = Wh + (u - y * pad);
-            l.A[y * p.RS + n] = make_float2(0.f, 0.f);
+            l.A[y * p.RS + n] = cf_zero();
         }
     }
     __syncthreads();
@@ -694,24 +711,24 @@ __device__ __forceinline__ void psf_conv_body(const PsfArgs &a, const FftPlan &p
     FFT_STAMP(30);
     const int H = p.H, W = p.W, M = p.M, HW = H * W, Wh = W >> 1;           // W even (checked on the host)
     const size_t plane = (size_t)s * B + b;
-    float2 *gp = (float2 *)(G + plane * HW);
+    cf *gp = (cf *)(G + plane * HW);
     const float2 *img = (const float2 *)(a.images + plane * HW);
     const float2 *wgt = a.weights ? (const float2 *)(a.weights + plane * HW) : nullptr;
     // model plane -> rows < H (pixel pairs), zeros up to column M
     const FftLds l = fft_lds_setup<NT>(fft_lds, p);
     constexpr int PF = SC_FFT_PF * SC_FFT_NT / NT;      // the same 8192 pairs in registers at kernel start
-    float2 mreg[PF];
+    cf mreg[PF];
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
         const int u = threadIdx.x + j * NT;
-        mreg[j] = u < H * Wh ? gp[u] : make_float2(0.f, 0.f);
+        mreg[j] = u < H * Wh ? gp[u] : cf_zero();
     }
     __shared__ double red[NT / SC_WAVE];
     {
         const float rcp = 1.0f / (float)M;
         for (int u = threadIdx.x; u < H * M; u += NT) {
             const int y = fast_div(u, rcp), n = u - y * M;
-            if (n >= Wh) l.A[y * p.RS + n] = make_float2(0.f, 0.f);
+            if (n >= Wh) l.A[y * p.RS + n] = cf_zero();
         }
         const float rcpw = 1.0f / (float)Wh;
 #pragma unroll

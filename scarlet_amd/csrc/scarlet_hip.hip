@@ -867,17 +867,22 @@ static bool fft_make_plan(int H, int W, int Py, int Px, FftPlan *p)
 static void fft_fill_tables(const FftPlan &p, std::vector<float2> &t)
 {
     const double tau = 6.283185307179586476925286766559;
+    const int NP = p.M / 2 + 1;
     t.assign(fft_table_float2s(p.Fy, p.M), make_float2(0.f, 0.f));
-    float2 *twy = t.data(), *twm = twy + p.Fy, *twx = twm + p.M;
-    for (int j = 0; j < p.Fy; ++j) twy[j] = make_float2((float)cos(tau * j / p.Fy), (float)-sin(tau * j / p.Fy));
-    for (int j = 0; j < p.M; ++j) twm[j] = make_float2((float)cos(tau * j / p.M), (float)-sin(tau * j / p.M));
-    for (int k = 0; k <= p.M / 2; ++k) twx[k] = make_float2((float)cos(tau * k / p.Fx), (float)-sin(tau * k / p.Fx));
-    unsigned short *posx = (unsigned short *)(twx + (p.M / 2 + 1));
+    // a twiddle w = c + i s is stored as (c, s, -s, s): fftconv.h cmul_t
+    struct Tw4 { float c, s, ns, s2; };
+    auto tw = [&](double num, double den) {
+        const float c = (float)cos(tau * num / den), sn = (float)-sin(tau * num / den);
+        return Tw4{c, sn, -sn, sn};
+    };
+    Tw4 *twy = (Tw4 *)t.data(), *twm = twy + p.Fy, *twx = twm + p.M, *twp = twx + NP;
+    for (int j = 0; j < p.Fy; ++j) twy[j] = tw(j, p.Fy);
+    for (int j = 0; j < p.M; ++j) twm[j] = tw(j, p.M);
+    for (int k = 0; k < NP; ++k) twx[k] = tw(k, p.Fx);
+    unsigned short *posx = (unsigned short *)(twp + NP);
     for (int k = 0; k < p.M; ++k) posx[k] = (unsigned short)(p.R2x * (k % p.R1x) + k / p.R1x);
     // the column pairs (k, M - k), k = 0 .. M/2, in the order of their first member's position (fftconv.h FftPair)
-    const int NP = p.M / 2 + 1;
-    float2 *twp = twx + NP + (p.M + 3) / 4;
-    FftPair *pair = (FftPair *)(twp + NP);
+    FftPair *pair = (FftPair *)(t.data() + 2 * (p.Fy + p.M + 2 * NP) + (p.M + 3) / 4);
     std::vector<int> order(NP);
     for (int k = 0; k < NP; ++k) order[k] = k;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return posx[a] < posx[b]; });
