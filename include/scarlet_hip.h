@@ -322,6 +322,10 @@ int scarlet_check_convergence(scarlet_batch *b, double e_rel, void *stream);
 /* diagnostics (STAMPS switch on): byte offset inside b->workspace of the convolution kernel's phase stamps
  * ([S][B][32] int64 shader-clock values, written by every k_psf_conv launch), or -1 */
 int64_t scarlet_debug_psf_stamps_offset(const scarlet_batch *b);
+/* diagnostics: plan of the LDS-resident convolution (fftconv.h) for this batch: {H, W, Fy, Fx, M, RS, R1y, R2y, R1x, R2x,
+ * oky, okx, image staged in LDS, exact-shape instance, LDS bytes, 0}; 0, or -1 when the batch takes another path.
+ * Host-only: no device call. */
+int scarlet_debug_psf_plan(const scarlet_batch *b, int32_t *out16);
 int scarlet_profile_begin(int max_iterations);
 int scarlet_profile_end(double total_ms[8], int64_t launches[8]);
 /* the same with both counts: `iterations` = iterations covered by the class's launches (what

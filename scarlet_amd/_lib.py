@@ -93,6 +93,7 @@ _SIGNATURES = {
     "scarlet_source_update": (c_int, [POINTER(ScarletBatch), c_int, _P]),
     "scarlet_check_convergence": (c_int, [POINTER(ScarletBatch), c_double, _P]),
     "scarlet_debug_psf_stamps_offset": (c_int64, [_P]),
+    "scarlet_debug_psf_plan": (c_int, [_P, _P]),
     "scarlet_profile_begin": (c_int, [c_int]),
     "scarlet_profile_end": (c_int, [_P, _P]),
     "scarlet_profile_end_ex": (c_int, [_P, _P, _P]),

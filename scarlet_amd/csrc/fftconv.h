@@ -680,18 +680,18 @@ __device__ __forceinline__ void fft_conv_core(const FftLds &l, const FftPlan &p,
 // one streaming read of the K morphologies per SCENE -- building the plane here costs K plane reads per
 // BAND through this CU's load path, a third of the kernel when measured) and the gradient planes on exit.
 // grid: one workgroup per (scene, band); consecutive scenes go to consecutive XCDs.
-// XP: the exact-shape instance for BASELINE config 3 (128 x 128 frames, 41 x 41 kernel: Fy = Fx = 160 = 10 x 16, M = 80 =
-// 16 x 5) -- the plan's shapes and radices are compile-time facts (index arithmetic and radix dispatch fold away: the
-// kernel fits 128 VGPRs) and the workgroup has NT = 1024 threads: the passes of 640 - 810 items take ONE round of
-// threads instead of two half-empty ones, at four waves per SIMD instead of two.
+// XP: the exact-shape instance for BASELINE config 3 (128 x 128 frames, 41 x 41 kernel whose offset in the reference's padded
+// array is -20: F = 150 = 10 x 15 both ways, M = 75 = 5 x 15) -- the plan's shapes and radices are compile-time facts (index
+// arithmetic and radix dispatch fold away: the kernel fits 128 VGPRs) and the workgroup has NT = 1024 threads: the passes
+// of 570 - 760 items take ONE round of threads instead of two half-empty ones, at four waves per SIMD instead of two.
 template <bool XP, int NT>
 __device__ __forceinline__ void psf_conv_body(const PsfArgs &a, const FftPlan &p_in, float *G, long long *stamps_all)
 {
     FftPlan p = p_in;
     if (XP) {
-        p.H = 128; p.W = 128; p.Fy = 160; p.Fx = 160; p.M = 80; p.RS = 81;
-        p.R1y = 10; p.R2y = 16; p.R1x = 16; p.R2x = 5; p.dma_image = 1;
-        p.tab_off = fft_tab_off(160, 81, 128, 128, true);
+        p.H = 128; p.W = 128; p.Fy = 150; p.Fx = 150; p.M = 75; p.RS = 76;
+        p.R1y = 10; p.R2y = 15; p.R1x = 5; p.R2x = 15; p.dma_image = 1;
+        p.tab_off = fft_tab_off(150, 76, 128, 128, true);
     }
     extern __shared__ __align__(16) float2 fft_lds[];
     const int B = a.B;

@@ -903,6 +903,18 @@ static bool psf_lds_possible(const scarlet_batch *b, FftPlan *p)
     return fft_make_plan(b->H, b->W, b->psf_h, b->psf_w, p);
 }
 
+// k_psf_conv's view of the plan: where the image is staged; true when the exact-shape instance applies
+static bool psf_conv_finish_plan(const scarlet_batch *b, FftPlan *fp)
+{
+    // the image plane is staged in LDS by LDS-DMA when it fits behind the H data rows (16-byte pieces)
+    fp->dma_image = ((b->H * b->W) % 4 == 0 &&
+                     fft_lds_bytes(fp->Fy, fp->M, fp->RS, b->H, b->W, true) <= LDS_LIMIT - 1024) ? 1 : 0;
+    fp->tab_off = fft_tab_off(fp->Fy, fp->RS, b->H, b->W, fp->dma_image != 0);
+    // BASELINE config 3's plan has an exact-shape instance with 1024 threads per workgroup (fftconv.h)
+    return fp->H == 128 && fp->W == 128 && fp->Fy == 150 && fp->Fx == 150 && fp->M == 75 && fp->RS == 76 && fp->R1y == 10 &&
+           fp->R2y == 15 && fp->R1x == 5 && fp->R2x == 15 && fp->dma_image == 1 && !opt(OPT_NO_EXACT);
+}
+
 // Workspace of a batch with a PSF.  Which convolution runs is a function of the shapes alone -- the
 // LDS-resident transform whenever the half-spectrum plane fits LDS, batched hipFFT otherwise (frames
 // beyond ~150 + P pixels) -- except for the diagnostic switch PSF_HIPFFT, which forces the library path
@@ -970,6 +982,20 @@ static void split_views(const scarlet_batch *b, scarlet_batch v[2])
 
 // diagnostics (STAMPS switch): byte offset, inside the batch's workspace, of k_psf_conv's phase stamps
 // ([S][B][32] int64 shader-clock values), or -1 when the batch has none
+// diagnostics: the plan of the LDS-resident convolution for this batch, 16 ints {H, W, Fy, Fx, M, RS, R1y, R2y, R1x, R2x,
+// oky, okx, dma_image, exact-shape instance, LDS bytes, 0}; returns 0, or -1 when the batch takes another path
+extern "C" int scarlet_debug_psf_plan(const scarlet_batch *b, int32_t *out16)
+{
+    if (!b || !out16 || !b->diff_kernel || b->psf_h <= 0 || b->psf_w <= 0) return -1;
+    FftPlan p;
+    if (!psf_use_lds(b, &p)) return -1;
+    const bool x = psf_conv_finish_plan(b, &p);
+    const int v[16] = {p.H, p.W, p.Fy, p.Fx, p.M, p.RS, p.R1y, p.R2y, p.R1x, p.R2x, p.oky, p.okx, p.dma_image, x ? 1 : 0,
+                       (int)fft_lds_bytes(p.Fy, p.M, p.RS, b->H, b->W, p.dma_image != 0), 0};
+    for (int i = 0; i < 16; ++i) out16[i] = v[i];
+    return 0;
+}
+
 extern "C" int64_t scarlet_debug_psf_stamps_offset(const scarlet_batch *b)
 {
     if (!b || !b->diff_kernel || b->psf_h <= 0 || b->psf_w <= 0 || !opt(OPT_STAMPS)) return -1;
@@ -1208,10 +1234,7 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         // one kernel: model, render, residual + loss, adjoint -> compact gradient planes G [S][B][H][W] in `real`
         fp.tables = (const float2 *)((char *)b->workspace + l.lds_tables);
         a.khat = (const float2 *)((char *)b->workspace + l.lds_khat);
-        // the image plane is staged in LDS by LDS-DMA when it fits behind the H data rows (16-byte pieces)
-        fp.dma_image = ((b->H * b->W) % 4 == 0 &&
-                        fft_lds_bytes(fp.Fy, fp.M, fp.RS, b->H, b->W, true) <= LDS_LIMIT - 1024) ? 1 : 0;
-        fp.tab_off = fft_tab_off(fp.Fy, fp.RS, b->H, b->W, fp.dma_image != 0);
+        const bool x128 = psf_conv_finish_plan(b, &fp);
         const size_t lds = fft_lds_bytes(fp.Fy, fp.M, fp.RS, b->H, b->W, fp.dma_image != 0);
         if ((rc = allow_lds(k_psf_conv, lds))) return rc;
         const int groups = (b->S + 7) / 8;
@@ -1228,9 +1251,6 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
             hipLaunchKernelGGL(k_psf_model, dim3((b->H * b->W + SC_BLOCK - 1) / SC_BLOCK, b->S), dim3(SC_BLOCK), 0, st, a);
         long long *stamps = opt(OPT_STAMPS) ? (long long *)((char *)b->workspace + l.stamps) : nullptr;
         fp.stagger_wgs = 0;
-        // BASELINE config 3's plan has an exact-shape instance with 1024 threads per workgroup (fftconv.h)
-        const bool x128 = fp.H == 128 && fp.W == 128 && fp.Fy == 160 && fp.Fx == 160 && fp.M == 80 && fp.RS == 81 && fp.R1y == 10 &&
-                          fp.R2y == 16 && fp.R1x == 16 && fp.R2x == 5 && fp.dma_image == 1 && !opt(OPT_NO_EXACT);
         if (x128) {
             if ((rc = allow_lds(k_psf_conv_x128, lds))) return rc;
             hipLaunchKernelGGL(k_psf_conv_x128, dim3(groups * 8 * b->B), dim3(SC_FFT_NT_X), lds, st, a, fp, a.real, stamps);
