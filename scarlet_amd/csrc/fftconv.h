@@ -611,36 +611,109 @@ __device__ __forceinline__ void fft_dma_image(const FftLds &l, const FftPlan &p,
                                              (__attribute__((address_space(3))) void *)(stage + (size_t)c0 * 4), 16, 0, 0);
     }
 }
-// d = w (render - image), loss, w d back into the plane (columns >= W/2 of the rows stay zero from the build);
-// `pf` holds the first SC_FFT_PF * SC_FFT_NT pairs, the rest (larger frames) is read here
-template <int NT = SC_FFT_NT>
-__device__ __forceinline__ void fft_residual(const FftLds &l, const FftPlan &p, const float2 *img,
-                                             const float2 *wgt, float wscalar, double &loss)
+// ---- row passes fused with what happens to the pixels (tools/fft_proto.py: the last inverse row pass A^-1 of item
+// (row y, n2) leaves the R1x pixel pairs n = n2 + R2x n1 of its row in registers, and the first forward row pass A
+// of the next transform starts from exactly those positions): the residual, the model-plane load and the store of G
+// ride on the row passes instead of being LDS round trips of their own (3 passes = barriers less per plane).
+// rows_Ainv_resid_A: render's last inverse row pass -> d = w (render - image), loss, w d -> adjoint's first row pass
+template <int R, int NT>
+__device__ __forceinline__ void rows_Ainv_resid_A(const FftLds &l, const FftPlan &p, const float2 *img, const float2 *wgt,
+                                                  float wscalar, double &loss)
 {
-    const int Wh = p.W >> 1, npairs = p.H * Wh;
-    const float rcp = 1.0f / (float)Wh;
+    const int R2 = p.R2x, RS = p.RS, Wh = p.W >> 1;
+    const int total = p.H * R2;
+    const float rcp = 1.0f / (float)R2;
     const cf *stage = l.A + p.H * p.RS;               // the image as the LDS-DMA left it: [H][W/2] pairs, lane-linear
     const cf *imgv = reinterpret_cast<const cf *>(img), *wgtv = reinterpret_cast<const cf *>(wgt);
-    for (int u = threadIdx.x; u < npairs; u += NT) {
-        const int y = fast_div(u, rcp), n = u - y * Wh;
-        cf *q = l.A + y * p.RS + n;
-        const cf r = *q, im = p.dma_image ? stage[u] : imgv[u];
-        const cf w = wgt ? wgtv[u] : cf{wscalar, wscalar};
-        const cf d = w * (r - im);
-        loss += (double)d.x * (double)d.x + (double)d.y * (double)d.y;
-        *q = w * d;
-    }
-    // the inverse transform leaves (tiny) values in columns W/2 .. M-1 of the rows: the adjoint's input is zero there
-    const int pad = p.M - Wh;
-    if (pad > 0) {
-        const float rcp2 = 1.0f / (float)pad;
-        for (int u = threadIdx.x; u < p.H * pad; u += NT) {
-            const int y = fast_div(u, rcp2), n = Wh + (u - y * pad);
-            l.A[y * p.RS + n] = cf_zero();
+    for (int u = threadIdx.x; u < total; u += NT) {
+        const int y = fast_div(u, rcp), n2 = u - y * R2;
+        cf *q = l.A + y * RS + n2;
+        cf v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = q[k * R2];
+        Dft<R, true>::run(v);
+#pragma unroll
+        for (int n1 = 0; n1 < R; ++n1) {
+            const int n = n2 + n1 * R2;
+            if (n < Wh) {
+                const int e = y * Wh + n;
+                const cf im = p.dma_image ? stage[e] : imgv[e];
+                const cf w = wgt ? wgtv[e] : cf{wscalar, wscalar};
+                const cf d = w * (v[n1] - im);
+                loss += (double)d.x * (double)d.x + (double)d.y * (double)d.y;
+                v[n1] = w * d;
+            } else
+                v[n1] = cf_zero();                   // columns W/2 .. M-1: the adjoint's input is zero there
         }
+        Dft<R, false>::run(v);
+#pragma unroll
+        for (int k = 1; k < R; ++k) v[k] = cmul_t(v[k], l.twm[n2 * k]);
+#pragma unroll
+        for (int k = 0; k < R; ++k) q[k * R2] = v[k];
     }
     __syncthreads();
 }
+// rows_Ainv_store: the adjoint's last inverse row pass -> G in global memory
+template <int R, int NT>
+__device__ __forceinline__ void rows_Ainv_store(const FftLds &l, const FftPlan &p, cf *gp)
+{
+    const int R2 = p.R2x, RS = p.RS, Wh = p.W >> 1;
+    const int total = p.H * R2;
+    const float rcp = 1.0f / (float)R2;
+    for (int u = threadIdx.x; u < total; u += NT) {
+        const int y = fast_div(u, rcp), n2 = u - y * R2;
+        const cf *q = l.A + y * RS + n2;
+        cf v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = q[k * R2];
+        Dft<R, true>::run(v);
+#pragma unroll
+        for (int n1 = 0; n1 < R; ++n1) {
+            const int n = n2 + n1 * R2;
+            if (n < Wh) gp[y * Wh + n] = v[n1];
+        }
+    }
+}
+// rows_load_A: model plane (global, pixel pairs) -> first forward row pass.  The loads of ALL of a thread's items are
+// issued before anything else the kernel does (tables, ...): NI = items per thread, compile-time (exact-shape instance)
+template <int R, int NT, int NI>
+struct RowsLoadA {
+    cf v[NI][R];
+    __device__ __forceinline__ void request(const FftPlan &p, const cf *gp)
+    {
+        const int R2 = p.R2x, Wh = p.W >> 1, total = p.H * R2;
+        const float rcp = 1.0f / (float)R2;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int u = threadIdx.x + i * NT;
+            const int y = fast_div(u, rcp), n2 = u - y * R2;
+#pragma unroll
+            for (int n1 = 0; n1 < R; ++n1) {
+                const int n = n2 + n1 * R2;
+                v[i][n1] = (u < total && n < Wh) ? gp[y * Wh + n] : cf_zero();
+            }
+        }
+    }
+    __device__ __forceinline__ void run(const FftLds &l, const FftPlan &p)
+    {
+        const int R2 = p.R2x, RS = p.RS, total = p.H * R2;
+        const float rcp = 1.0f / (float)R2;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int u = threadIdx.x + i * NT;
+            if (u < total) {
+                const int y = fast_div(u, rcp), n2 = u - y * R2;
+                cf *q = l.A + y * RS + n2;
+                Dft<R, false>::run(v[i]);
+#pragma unroll
+                for (int k = 1; k < R; ++k) v[i][k] = cmul_t(v[i][k], l.twm[n2 * k]);
+#pragma unroll
+                for (int k = 0; k < R; ++k) q[k * R2] = v[i][k];
+            }
+        }
+        __syncthreads();
+    }
+};
 
 #define SC_FFT_DISPATCH(R_, CALL)                                                                                  \
     switch (R_) {                                                                                                  \
@@ -652,14 +725,12 @@ __device__ __forceinline__ void fft_residual(const FftLds &l, const FftPlan &p, 
     case 16: { constexpr int RR = 16; CALL; } break;  default: break;                                              \
     }
 
-// one convolution up to (not including) the last inverse row pass: rows fwd, columns (fused), rows B^-1
+// one convolution between its first forward row pass and its last inverse one: rows B, columns (fused), rows B^-1
 #define FFT_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 template <bool CONJ, int NT = SC_FFT_NT, typename AfterColumns>
-__device__ __forceinline__ void fft_conv_core(const FftLds &l, const FftPlan &p, const float2 *khat, long long *stamps,
-                                              AfterColumns &&after_columns)
+__device__ __forceinline__ void fft_conv_middle(const FftLds &l, const FftPlan &p, const float2 *khat, long long *stamps,
+                                                AfterColumns &&after_columns)
 {
-    fft_pass<false, NT>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, true, false);                     // rows A
-    FFT_STAMP(0);
     fft_pass<false, NT>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, false, false);                    // rows B
     FFT_STAMP(1);
     SC_FFT_DISPATCH(p.R1y, (cols_A_untangle<RR, NT>(l, p)))
@@ -671,8 +742,6 @@ __device__ __forceinline__ void fft_conv_core(const FftLds &l, const FftPlan &p,
     after_columns();                     // the low-register-pressure row passes follow: global loads go here
     fft_pass<true, NT>(p.R2x, l.A, p.H, p.RS, p.R1x, p.R2x, 1, l.twm, true, false);                      // rows B^-1
     FFT_STAMP(5);
-    fft_pass<true, NT>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, false, false);                     // rows A^-1
-    FFT_STAMP(6);
 }
 
 // the iteration's convolution pair: G_b = render^T( w^2 (render(model)_b - image_b) ), loss_b.
@@ -714,17 +783,23 @@ __device__ __forceinline__ void psf_conv_body(const PsfArgs &a, const FftPlan &p
     cf *gp = (cf *)(G + plane * HW);
     const float2 *img = (const float2 *)(a.images + plane * HW);
     const float2 *wgt = a.weights ? (const float2 *)(a.weights + plane * HW) : nullptr;
-    // model plane -> rows < H (pixel pairs), zeros up to column M
-    const FftLds l = fft_lds_setup<NT>(fft_lds, p);
-    constexpr int PF = SC_FFT_PF * SC_FFT_NT / NT;      // the same 8192 pairs in registers at kernel start
+    // Exact-shape instance: the model plane goes from global memory straight into the first forward row pass (requested
+    // here, before the tables are staged); otherwise it is written to rows < H as pixel pairs, zeros up to column M
+    constexpr int NI1 = XP ? (128 * 15 + NT - 1) / NT : 1;
+    RowsLoadA<XP ? 5 : 1, NT, NI1> first;
+    if constexpr (XP) first.request(p, gp);
+    constexpr int PF = XP ? 1 : SC_FFT_PF * SC_FFT_NT / NT;      // (generic: 8192 pairs in registers at kernel start)
     cf mreg[PF];
+    if constexpr (!XP) {
 #pragma unroll
-    for (int j = 0; j < PF; ++j) {
-        const int u = threadIdx.x + j * NT;
-        mreg[j] = u < H * Wh ? gp[u] : cf_zero();
+        for (int j = 0; j < PF; ++j) {
+            const int u = threadIdx.x + j * NT;
+            mreg[j] = u < H * Wh ? gp[u] : cf_zero();
+        }
     }
+    const FftLds l = fft_lds_setup<NT>(fft_lds, p);
     __shared__ double red[NT / SC_WAVE];
-    {
+    if constexpr (!XP) {
         const float rcp = 1.0f / (float)M;
         for (int u = threadIdx.x; u < H * M; u += NT) {
             const int y = fast_div(u, rcp), n = u - y * M;
@@ -745,18 +820,15 @@ __device__ __forceinline__ void psf_conv_body(const PsfArgs &a, const FftPlan &p
     const float2 *khat = a.khat + (size_t)(a.khat_per_scene ? s * B + b : b) * p.Fy * (M + 1);
     double loss = 0;
     FFT_STAMP(31);
+    if constexpr (XP) first.run(l, p);
+    else fft_pass<false, NT>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, true, false);                // rows A
+    FFT_STAMP(0);
     // the image is requested after the render's column stage: in flight under the next row pass
-    fft_conv_core<false, NT>(l, p, khat, stamps, [&]() { if (p.dma_image) fft_dma_image<NT>(l, p, a.images + plane * HW); });
-    fft_residual<NT>(l, p, img, wgt, a.weight_scalar, loss);
-    FFT_STAMP(7);
-    fft_conv_core<true, NT>(l, p, khat, stamps ? stamps + 8 : nullptr, []() {});
-    {
-        const float rcpw = 1.0f / (float)Wh;
-        for (int u = threadIdx.x; u < H * Wh; u += NT) {
-            const int y = fast_div(u, rcpw), n = u - y * Wh;
-            gp[u] = l.A[y * p.RS + n];
-        }
-    }
+    fft_conv_middle<false, NT>(l, p, khat, stamps, [&]() { if (p.dma_image) fft_dma_image<NT>(l, p, a.images + plane * HW); });
+    SC_FFT_DISPATCH(p.R1x, (rows_Ainv_resid_A<RR, NT>(l, p, img, wgt, a.weight_scalar, loss)))
+    FFT_STAMP(8);
+    fft_conv_middle<true, NT>(l, p, khat, stamps ? stamps + 8 : nullptr, []() {});
+    SC_FFT_DISPATCH(p.R1x, (rows_Ainv_store<RR, NT>(l, p, gp)))
     FFT_STAMP(15);
     // loss of the plane
     loss = wave_sum(loss);

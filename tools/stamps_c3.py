@@ -16,14 +16,12 @@ assert off >= 0, "no stamps region (SCARLET_STAMPS=1 must be set before the libr
 st = ws[off:off + n * 8].view(torch.int64).view(-1, 32).cpu().numpy()
 ok = st[:, 15] > 0
 st = st[ok]
-names = ["start", "load model plane", "rowsA", "rowsB", "colsA+unt", "colsB*K*Binv", "colsAinv+tangle", "rowsBinv", "rowsAinv", "residual",
-         "rowsA", "rowsB", "colsA+unt", "colsB*K*Binv", "colsAinv+tangle", "rowsBinv", "rowsAinv", "store G"]
-seq = [30, 31, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]
+names = ["start", "tables (+ model plane)", "rowsA (+ model load)", "rowsB", "colsA+unt", "colsB*K*Binv", "colsAinv+tangle", "rowsBinv",
+         "rowsAinv+residual+rowsA", "rowsB", "colsA+unt", "colsB*K*Binv", "colsAinv+tangle", "rowsBinv", "rowsAinv+store G"]
+seq = [30, 31, 0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 15]
 prev = st[:, 30]
 tot = (st[:, 15] - st[:, 30]).mean()
 print("planes stamped:", len(st), " total cycles per plane: %.0f" % tot)
-print("start-up detail (cycles since kernel start): prefetch issued %.0f, tables in LDS %.0f, zero fill %.0f, model stored %.0f, image requested %.0f, barrier %.0f" % tuple(
-    (st[:, i] - st[:, 30]).mean() for i in (16, 17, 18, 19, 20, 31)))
 for nm, i in zip(names[1:], seq[1:]):
     d = (st[:, i] - prev).mean(); prev = st[:, i]
     print("%-24s %8.0f  %5.1f%%" % (nm, d, 100 * d / tot))
