@@ -477,3 +477,43 @@ def test_config3_shape_twenty_five_iterations_vs_oracle(scarlet):
                     rel_err(b.sed_current[i].cpu().numpy(), np.array([s.sed for s in sc.sources])),
                     rel_err(b.mse(i), sc.mse))
     assert worst < 1e-5, worst
+
+
+def test_exact_shape_convolution_instance_equals_the_generic_kernel(scarlet):
+    """BASELINE config 3's plan (128 x 128 frame, 41 x 41 kernel: F = 150 = 10 x 15, M = 75 = 5 x 15) has an exact-shape
+    instance of the convolution kernel (k_psf_conv_x128: 1024 threads, shapes and radices as compile-time constants, the
+    model-plane load fused into the first row pass).  (a) The host-side plan report says the instance applies to this
+    shape -- an instance written for a plan the shape does not have is never launched, which is how a first version went
+    unnoticed.  (b) Same codelets, same operands: everything but the loss (a sum whose order follows the thread
+    count) is bit-identical to the generic kernel (NO_EXACT also switches the exact-shape box instances, themselves
+    bit-identical to the generic ones: test_gpu_engine)."""
+    import ctypes
+    from scarlet_amd import synth, fft as fftmod, _lib
+    B, H, W, K, S = 5, 128, 128, 8, 9
+    obs_psfs = np.array([synth.gaussian_psf((41, 41), 1.2 + 0.15 * b) for b in range(B)])
+    model_psf = synth.gaussian_psf((41, 41), 0.9)
+    diff = np.asarray(fftmod.match_psfs(fftmod.Fourier(obs_psfs.astype(np.float32)),
+                                        fftmod.Fourier(model_psf[None].astype(np.float32))).image, dtype=np.float32)
+    scenes = [synth.make_scene(700 + i, B=B, H=H, W=W, K=K, psfs=obs_psfs) for i in range(S)]
+    out = []
+    for generic in (1, 0):
+        _lib.set_option("NO_EXACT", generic)
+        try:
+            b = scarlet.BlendBatch(np.stack([s["images"] for s in scenes]), np.stack([s["centers"] for s in scenes]),
+                                   centroid_weight=model_psf.astype(np.float32))
+            b.set_diff_kernel(diff)
+            plan = (ctypes.c_int32 * 16)()
+            assert _lib.lib.scarlet_debug_psf_plan(ctypes.byref(b._c), plan) == 0
+            assert list(plan[:10]) == [128, 128, 150, 150, 75, 76, 10, 15, 5, 15]
+            assert plan[13] == (0 if generic else 1)
+            b.init_extended(np.ones(B) * 0.1)
+            b.fit(9, e_rel=1e-3)
+            torch.cuda.synchronize()
+            assert int(b.status.abs().sum().item()) == 0
+            out.append((npy(b.morph_current), npy(b.sed_current), npy(b.it), npy(b.centers), npy(b.lipschitz),
+                        np.array([b.mse(i) for i in range(S)])))
+        finally:
+            _lib.set_option("NO_EXACT", 0)
+    for x, y in zip(out[0][:5], out[1][:5]):
+        assert_array_equal(x, y)
+    assert rel_err(out[0][5], out[1][5]) < 1e-6
