@@ -74,6 +74,34 @@ json.dump(out, open("gpurun_out/%s_pmc_traffic_k_fit2x.json" % tag, "w"), indent
 print({k: out[k] for k in ("kernel", "hbm_bytes_per_launch_and_iteration", "algorithmic_bytes_per_launch_and_iteration", "traffic_over_algorithmic")})
 PY
 
+# 4b. counters of config 3's convolution kernel (k_psf_conv_x128: one launch per half-batch of 2048 scenes), phase stamps
+bash tools/pmc_any.sh ${TAG}_c3conv k_psf_conv tools/pmc_run_c3.py > $O/${TAG}_pmc_c3conv.log 2>&1
+python - $TAG <<'PY'
+import json, os, sys
+tag = sys.argv[1]
+pm = json.load(open("gpurun_out/pmc_%s_c3conv.json" % tag))
+S = 4096 // 2
+out = {"command": "bash tools/pmc_any.sh <tag> k_psf_conv tools/pmc_run_c3.py  (rocprofv3 --kernel-trace --pmc <set>, separate passes; "
+                  "4096 scenes, launched by scarlet_fit as two half-batches of 2048)",
+       "kernel": pm.get("kernel"), "scenes_per_launch": S, "launches": pm.get("launches"),
+       "note": "FETCH_SIZE / WRITE_SIZE in KiB per launch; FETCH_SIZE x 2 on gfx950 for wide coalesced reads (guide, HBM section); "
+               "the kernel's own stream is one 64 KiB model plane + one 64 KiB image plane read and one 64 KiB gradient plane "
+               "written per (scene, band)",
+       "FETCH_SIZE_mean_KiB": pm.get("FETCH_SIZE"), "WRITE_SIZE_mean_KiB": pm.get("WRITE_SIZE"),
+       "hbm_read_bytes_per_launch": pm.get("hbm_read_bytes_x2_correction"), "hbm_write_bytes_per_launch": pm.get("hbm_write_bytes"),
+       "hbm_bytes_per_launch": pm.get("hbm_read_bytes_x2_correction", 0) + pm.get("hbm_write_bytes", 0),
+       "kernel_own_bytes_per_launch (model + image read, G written)": S * 5 * 3 * 128 * 128 * 4,
+       "algorithmic_bytes_per_launch (whole iteration, SURVEY 8d)": S * (4 * 128 * 128 * (5 + 16) + 8 * 8 * 5),
+       "sq_counters_per_launch": {k: v for k, v in pm.items() if k.startswith("SQ_")}}
+if "SQ_INSTS_VALU" in pm and "SQ_WAVES" in pm:
+    out["vector_instructions_per_wave"] = pm["SQ_INSTS_VALU"] / pm["SQ_WAVES"]
+json.dump(out, open("gpurun_out/%s_pmc_traffic_k_psf_conv.json" % tag, "w"), indent=1)
+print({k: out[k] for k in ("kernel", "hbm_bytes_per_launch", "vector_instructions_per_wave") if k in out})
+PY
+SCARLET_STAMPS=1 python tools/stamps_c3.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_stamps_k_psf_conv.txt
+SCARLET_STAMPS=1 SCARLET_NO_EXACT=1 python tools/stamps_c3.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_stamps_k_psf_conv_generic.txt
+tail -16 $O/${TAG}_stamps_k_psf_conv.txt
+
 # 5. launch-level diagnostics and phase stamps of k_fit2x
 SCARLET_STAMPS=1 python tools/occupancy.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_occupancy_k_fit2x.txt
 SCARLET_STAMPS=1 STAMP_PRE=11 STAMP_ITERS=33 python tools/stamps.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_stamps_k_fit2x.txt
