@@ -317,7 +317,10 @@ __device__ __forceinline__ void ub_component(const UpdateArgs &a, const int c, i
     UB_STAMP(5);
     // the previous morphology for the convergence sums: the first groups are requested now, under the sweep
     const float *gl = a.in_iteration ? a.morph[c0] + (size_t)c * HW : nullptr;
-    constexpr int NLAST = 16;
+#ifndef SC_UB_NLAST
+#define SC_UB_NLAST 8       // float4 groups of the previous morphology a thread requests ahead of the sweep (16: 39 - 51 spilled VGPRs)
+#endif
+    constexpr int NLAST = SC_UB_NLAST;
     float4 lastv[NLAST];
     const bool vec4 = (W & 3) == 0;
     if (vec4) {
