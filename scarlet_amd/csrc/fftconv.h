@@ -616,16 +616,18 @@ __device__ __forceinline__ void fft_dma_image(const FftLds &l, const FftPlan &p,
 // of the next transform starts from exactly those positions): the residual, the model-plane load and the store of G
 // ride on the row passes instead of being LDS round trips of their own (3 passes = barriers less per plane).
 // rows_Ainv_resid_A: render's last inverse row pass -> d = w (render - image), loss, w d -> adjoint's first row pass
-template <int R, int NT>
+// `pre` (NI > 0): the items' image pairs already in registers (ImagePairs below), [item of the thread][n1]; the thread's
+// items are then walked by a compile-time count
+template <int R, int NT, int NI = 0>
 __device__ __forceinline__ void rows_Ainv_resid_A(const FftLds &l, const FftPlan &p, const float2 *img, const float2 *wgt,
-                                                  float wscalar, double &loss)
+                                                  float wscalar, double &loss, const cf (*pre)[R] = nullptr)
 {
     const int R2 = p.R2x, RS = p.RS, Wh = p.W >> 1;
     const int total = p.H * R2;
     const float rcp = 1.0f / (float)R2;
     const cf *stage = l.A + p.H * p.RS;               // the image as the LDS-DMA left it: [H][W/2] pairs, lane-linear
     const cf *imgv = reinterpret_cast<const cf *>(img), *wgtv = reinterpret_cast<const cf *>(wgt);
-    for (int u = threadIdx.x; u < total; u += NT) {
+    auto item = [&](int u, const cf *mine) {
         const int y = fast_div(u, rcp), n2 = u - y * R2;
         cf *q = l.A + y * RS + n2;
         cf v[R];
@@ -637,7 +639,7 @@ __device__ __forceinline__ void rows_Ainv_resid_A(const FftLds &l, const FftPlan
             const int n = n2 + n1 * R2;
             if (n < Wh) {
                 const int e = y * Wh + n;
-                const cf im = p.dma_image ? stage[e] : imgv[e];
+                const cf im = mine ? mine[n1] : (p.dma_image ? stage[e] : imgv[e]);
                 const cf w = wgt ? wgtv[e] : cf{wscalar, wscalar};
                 const cf d = w * (v[n1] - im);
                 loss += (double)d.x * (double)d.x + (double)d.y * (double)d.y;
@@ -650,6 +652,15 @@ __device__ __forceinline__ void rows_Ainv_resid_A(const FftLds &l, const FftPlan
         for (int k = 1; k < R; ++k) v[k] = cmul_t(v[k], l.twm[n2 * k]);
 #pragma unroll
         for (int k = 0; k < R; ++k) q[k * R2] = v[k];
+    };
+    if constexpr (NI > 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int u = threadIdx.x + i * NT;
+            if (u < total) item(u, pre[i]);
+        }
+    } else {
+        for (int u = threadIdx.x; u < total; u += NT) item(u, nullptr);
     }
     __syncthreads();
 }
@@ -715,6 +726,28 @@ struct RowsLoadA {
     }
 };
 
+// the image pairs of a thread's items of rows_Ainv_resid_A, requested one pass ahead into registers (exact-shape instance:
+// no staging area in LDS -- the 64 KB it took are what lets the other pipeline's workgroups share the CU)
+template <int R, int NT, int NI>
+struct ImagePairs {
+    cf v[NI][R];
+    __device__ __forceinline__ void request(const FftPlan &p, const cf *img)
+    {
+        const int R2 = p.R2x, Wh = p.W >> 1, total = p.H * R2;
+        const float rcp = 1.0f / (float)R2;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int u = threadIdx.x + i * NT;
+            const int y = fast_div(u, rcp), n2 = u - y * R2;
+#pragma unroll
+            for (int n1 = 0; n1 < R; ++n1) {
+                const int n = n2 + n1 * R2;
+                v[i][n1] = (u < total && n < Wh) ? img[y * Wh + n] : cf_zero();
+            }
+        }
+    }
+};
+
 #define SC_FFT_DISPATCH(R_, CALL)                                                                                  \
     switch (R_) {                                                                                                  \
     case 4: { constexpr int RR = 4; CALL; } break;    case 5: { constexpr int RR = 5; CALL; } break;               \
@@ -744,6 +777,9 @@ __device__ __forceinline__ void fft_conv_middle(const FftLds &l, const FftPlan &
     FFT_STAMP(5);
 }
 
+#ifndef SC_X128_DMA
+#define SC_X128_DMA 0                // exact-shape instance: 1 = image staged in LDS by LDS-DMA (158 KB), 0 = in registers (97 KB)
+#endif
 // the iteration's convolution pair: G_b = render^T( w^2 (render(model)_b - image_b) ), loss_b.
 // `G` holds the model planes model_b = sum_k sed[k][b] morph[k] on entry ([S][B][H][W], written by k_psf_model:
 // one streaming read of the K morphologies per SCENE -- building the plane here costs K plane reads per
@@ -759,8 +795,8 @@ __device__ __forceinline__ void psf_conv_body(const PsfArgs &a, const FftPlan &p
     FftPlan p = p_in;
     if (XP) {
         p.H = 128; p.W = 128; p.Fy = 150; p.Fx = 150; p.M = 75; p.RS = 76;
-        p.R1y = 10; p.R2y = 15; p.R1x = 5; p.R2x = 15; p.dma_image = 1;
-        p.tab_off = fft_tab_off(150, 76, 128, 128, true);
+        p.R1y = 10; p.R2y = 15; p.R1x = 5; p.R2x = 15; p.dma_image = SC_X128_DMA;
+        p.tab_off = fft_tab_off(150, 76, 128, 128, SC_X128_DMA != 0);
     }
     extern __shared__ __align__(16) float2 fft_lds[];
     const int B = a.B;
@@ -824,8 +860,14 @@ __device__ __forceinline__ void psf_conv_body(const PsfArgs &a, const FftPlan &p
     else fft_pass<false, NT>(p.R1x, l.A, p.H, p.RS, p.R2x, 1, p.R2x, l.twm, true, false);                // rows A
     FFT_STAMP(0);
     // the image is requested after the render's column stage: in flight under the next row pass
-    fft_conv_middle<false, NT>(l, p, khat, stamps, [&]() { if (p.dma_image) fft_dma_image<NT>(l, p, a.images + plane * HW); });
-    SC_FFT_DISPATCH(p.R1x, (rows_Ainv_resid_A<RR, NT>(l, p, img, wgt, a.weight_scalar, loss)))
+    ImagePairs<XP ? 5 : 1, NT, NI1> ipairs;
+    constexpr bool IREG = XP && !SC_X128_DMA;
+    fft_conv_middle<false, NT>(l, p, khat, stamps, [&]() {
+        if (IREG) ipairs.request(p, reinterpret_cast<const cf *>(img));
+        else if (p.dma_image) fft_dma_image<NT>(l, p, a.images + plane * HW);
+    });
+    if constexpr (IREG) rows_Ainv_resid_A<5, NT, NI1>(l, p, img, wgt, a.weight_scalar, loss, ipairs.v);
+    else SC_FFT_DISPATCH(p.R1x, (rows_Ainv_resid_A<RR, NT>(l, p, img, wgt, a.weight_scalar, loss)))
     FFT_STAMP(8);
     fft_conv_middle<true, NT>(l, p, khat, stamps ? stamps + 8 : nullptr, []() {});
     SC_FFT_DISPATCH(p.R1x, (rows_Ainv_store<RR, NT>(l, p, gp)))
@@ -845,7 +887,9 @@ __global__ __launch_bounds__(SC_FFT_NT) void k_psf_conv(PsfArgs a, FftPlan p, fl
 {
     psf_conv_body<false, SC_FFT_NT>(a, p, G, stamps_all);
 }
+#ifndef SC_FFT_NT_X
 #define SC_FFT_NT_X 1024
+#endif
 __global__ __launch_bounds__(SC_FFT_NT_X) void k_psf_conv_x128(PsfArgs a, FftPlan p, float *G, long long *stamps_all)
 {
     psf_conv_body<true, SC_FFT_NT_X>(a, p, G, stamps_all);

@@ -1252,8 +1252,10 @@ static int backward_step_psf(scarlet_batch *b, int approximate_L, int raw_gradie
         long long *stamps = opt(OPT_STAMPS) ? (long long *)((char *)b->workspace + l.stamps) : nullptr;
         fp.stagger_wgs = 0;
         if (x128) {
-            if ((rc = allow_lds(k_psf_conv_x128, lds))) return rc;
-            hipLaunchKernelGGL(k_psf_conv_x128, dim3(groups * 8 * b->B), dim3(SC_FFT_NT_X), lds, st, a, fp, a.real, stamps);
+            // (the instance keeps the image in registers unless built with SC_X128_DMA: plane + tables only)
+            const size_t lds_x = fft_lds_bytes(fp.Fy, fp.M, fp.RS, b->H, b->W, SC_X128_DMA != 0);
+            if ((rc = allow_lds(k_psf_conv_x128, lds_x))) return rc;
+            hipLaunchKernelGGL(k_psf_conv_x128, dim3(groups * 8 * b->B), dim3(SC_FFT_NT_X), lds_x, st, a, fp, a.real, stamps);
         } else
         hipLaunchKernelGGL(k_psf_conv, dim3(groups * 8 * b->B), dim3(SC_FFT_NT), lds, st, a, fp, a.real, stamps);
         prof_stop(st);
