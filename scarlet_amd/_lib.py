@@ -25,6 +25,13 @@ if not os.path.exists(LIB_PATH):
         "scarlet_amd: {} not found.  The engine has no CPU fallback; build the HIP "
         "library first (make -C scarlet_amd/csrc).".format(LIB_PATH))
 
+# PyTorch first.  The torch wheel carries its own HIP / HSA runtime libraries and libscarlet_hip.so is linked against
+# the system's (/opt/rocm/lib): when the system copies are mapped into the process BEFORE torch's, every kernel launch of
+# this library later fails with "no ROCm-capable device is detected" (seen with `import scarlet_amd` as a script's first
+# import; tests/test_gpu_api.py::test_package_imported_before_torch).  torch owns device memory and streams for this
+# package anyway, so its runtime is the one to load first.
+import torch  # noqa: E402,F401  (import order matters, see above)
+
 lib = ctypes.CDLL(LIB_PATH)
 
 # error codes / enums (mirror include/scarlet_hip.h)

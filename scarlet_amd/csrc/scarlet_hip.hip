@@ -746,6 +746,9 @@ extern "C" int scarlet_profile_end(double total_ms[SC_NCLASS], int64_t launches[
 
 static int check_batch(const scarlet_batch *b)
 {
+    // Every entry point ends with a look at hipGetLastError(); that value is per thread and keeps whatever an EARLIER HIP
+    // call of the thread left there.  Start from a clean slate: what is reported is ours.
+    (void)hipGetLastError();
     if (!b) return set_err(SCARLET_E_ARG, "null batch");
     if (b->S <= 0 || b->K <= 0 || b->B <= 0 || b->H <= 0 || b->W <= 0) return set_err(SCARLET_E_ARG, "bad batch shape");
     if (b->K > SC_KBIG || b->B > SC_BMAX)

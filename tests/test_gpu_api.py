@@ -780,3 +780,25 @@ def test_multi_iteration_launch_survives_graph_capture(scarlet):
     np.testing.assert_array_equal(npy(b.sed_current), npy(ref.sed_current))
     np.testing.assert_array_equal(npy(b.mse_buf)[:, :12], npy(ref.mse_buf)[:, :12])
     np.testing.assert_array_equal(npy(b.flags), npy(ref.flags))
+
+
+@pytest.mark.gpu
+def test_package_imported_before_torch():
+    """`import scarlet_amd` as the FIRST import of a process (the README's example) must work: the package loads PyTorch --
+    and with it torch's own HIP runtime -- before its native library; in the other order every launch of the library failed
+    with "no ROCm-capable device is detected".  Runs in a child process (import order is a property of a fresh interpreter)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import scarlet_amd as scarlet\n"
+        "from scarlet_amd import synth\n"
+        "sc = synth.make_scene(11, B=5, H=64, W=64, K=4)\n"
+        "b = scarlet.BlendBatch(sc['images'][None], sc['centers'][None])\n"
+        "b.init_extended(np.ones(5) * 0.1)\n"
+        "b.fit(3, e_rel=0)\n"
+        "assert int(b.status.abs().sum().item()) == 0 and int(b.it[0].item()) == 3\n"
+        "print('ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
